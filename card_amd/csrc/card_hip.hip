@@ -1,0 +1,631 @@
+// libcard_hip.so - CARD reverse-diffusion sampler for MI355X (gfx950 / CDNA4).
+//
+// One persistent kernel runs all T timesteps of p_sample_loop (reference:
+// regression/diffusion_utils.py:107-119) for N independent (row, z) chains:
+//   * a wave owns a tile of 32 chains for the whole loop; y_t, y_0_hat, y_T_mean and the x part of the
+//     layer-1 input stay in registers for all T steps
+//   * activations are kept TRANSPOSED (feature x chain): a 32x32 fp32 MFMA accumulator of layer l is,
+//     register for register, the B operand of layer l+1 (v_mfma_f32_32x32x2_f32 sums over the
+//     accumulator's row index), so the whole MLP chains through registers with no cross-lane traffic
+//   * W1..W3, biases and W4 live in LDS for the whole kernel in "fragment order" (one ds_read_b128 per
+//     lane yields the A operands of four consecutive MFMAs, conflict-free); per-step gamma rows are staged
+//     through a small wave-private LDS slab, prefetched one step ahead
+//   * epilogue per element: xs = acc * (gamma*log2e); softplus/ln2 = xs > 20*log2e ? xs : log2(1 + exp2(xs))
+//     (ln2 is folded into the next layer's weights), i.e. F.softplus(beta=1, threshold=20)
+//   * noise: injected (validation) or Philox4x32-10 + Box-Muller keyed by (seed, element, draw)
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (explicit fmaf where fusion is wanted).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdarg.h>
+#include <math.h>
+#include <new>
+
+#include "card_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int kH = 128;            // hidden width (regression/model.py:32-35)
+constexpr int kWaves = 8;          // waves per workgroup: 2 per SIMD, one workgroup per CU
+constexpr int kThreads = kWaves * 64;
+constexpr int kTileM = 32;         // chains per wave tile (the MFMA's 32 columns)
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr float kSpThresh = 20.0f * 1.4426950408889634f;  // softplus threshold 20 in log2 units
+
+// LDS image (floats), copied verbatim from the packed device buffer at kernel start.
+constexpr int kOffW2 = 0;                 // 128x128 in fragment order
+constexpr int kOffW3 = kH * kH;           // 128x128 in fragment order
+constexpr int kOffB = 2 * kH * kH;        // b1 | b2 | b3
+constexpr int kOffW4 = kOffB + 3 * kH;    // W4 * ln2
+constexpr int kOffB4 = kOffW4 + kH;       // b4 (+3 pad)
+constexpr int kOffW1 = kOffB4 + 4;        // 128 x K1 in fragment order
+__host__ __device__ constexpr int img_floats(int k1) { return kOffW1 + kH * k1; }
+constexpr int kGammaRow = 3 * kH;         // one timestep's gamma*log2e for the 3 layers
+
+struct RunParams {
+    const float* wpk;     // packed LDS image
+    const float* gtab;    // (n_embed, 3, 128) gamma * log2e
+    const float* coef;    // (T, 8)
+    const float* x;
+    const float* y0hat;
+    const float* ytmean;
+    const float* y_init;
+    const float* noise;
+    float* out;
+    const int* state_slot;
+    long long N;          // total rows (stride of one output/noise slab)
+    long long n_begin;    // this launch covers rows [n_begin, n_end)
+    long long n_end;
+    unsigned long long seed;
+    unsigned long long elem_offset;
+    int T, t_hi, t_lo;
+    int x_dim, cat_x, cat_y_pred;
+    int out_mode;
+    int eps_only;         // write eps_theta(y_init, t_hi) and stop
+};
+
+// ------------------------------------------------------------------------------------------------
+// RNG: Philox4x32-10 (Salmon et al. 2011) + Box-Muller.  Restated in oracle/card_oracle.py:philox_normal.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&o)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+__device__ __forceinline__ float u01(uint32_t r) { return ((float)(r >> 9) + 0.5f) * 1.1920928955078125e-07f; }
+
+// four standard normals for (element, draw block)
+__device__ __forceinline__ void philox_normal4(unsigned long long seed, unsigned long long elem, uint32_t block,
+                                               float (&z)[4]) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)elem, (uint32_t)(elem >> 32), block, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const float rad = sqrtf(-2.0f * logf(u01(r[2 * p])));
+        float s, c;
+        sincospif(2.0f * u01(r[2 * p + 1]), &s, &c);
+        z[2 * p] = rad * c;
+        z[2 * p + 1] = rad * s;
+    }
+}
+
+__device__ __forceinline__ float pick4(const float (&z)[4], int i) {
+    return i == 0 ? z[0] : (i == 1 ? z[1] : (i == 2 ? z[2] : z[3]));
+}
+
+// softplus(x)/ln2 with x given in log2 units: F.softplus(beta=1, threshold=20) (regression/model.py:48-50)
+__device__ __forceinline__ float softplus_l2(float xs) {
+    const float e = __builtin_amdgcn_exp2f(xs);
+    const float l = __builtin_amdgcn_logf(1.0f + e);
+    return xs > kSpThresh ? xs : l;
+}
+
+__device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// One ConditionalLinear + softplus with a 128-wide input held in registers (hin = previous layer's
+// accumulators).  wl: packed weights, bl: bias, gl: this step's gamma*log2e (all LDS, pre-offset by lane).
+__device__ __forceinline__ void layer_hidden(const float* wl, const float* bl, const float* gl, const f32x16 (&hin)[4],
+                                             f32x16 (&hout)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = lds4(bl + 32 * j + 8 * q);
+            acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 a = lds4(wl + (((j * 4 + jj) * 4 + q) * 64) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], hin[jj][4 * q + e], acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 g = lds4(gl + 32 * j + 8 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hout[j][4 * q + e] = softplus_l2(acc[4 * q + e] * g[e]);
+        }
+    }
+}
+
+template <int K1>
+__device__ __forceinline__ void layer_first(const float* wl, const float* bl, const float* gl, const float (&h0)[K1 / 2],
+                                            f32x16 (&hout)[4]) {
+    constexpr int NQ = K1 / 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = lds4(bl + 32 * j + 8 * q);
+            acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const f32x4 a = lds4(wl + ((j * NQ + q) * 64) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], h0[4 * q + e], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 g = lds4(gl + 32 * j + 8 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hout[j][4 * q + e] = softplus_l2(acc[4 * q + e] * g[e]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The persistent sampler kernel (CARD_VARIANT_GUIDED, y_dim = 1, H = 128, layer-1 K padded to K1).
+// ------------------------------------------------------------------------------------------------
+template <int K1>
+__global__ __launch_bounds__(kThreads, 2) void card_sample_guided_kernel(const RunParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int IMG = img_floats(K1);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid * 4; i < IMG; i += kThreads * 4)
+        *reinterpret_cast<f32x4*>(&lds[i]) = *reinterpret_cast<const f32x4*>(&p.wpk[i]);
+    __syncthreads();
+
+    const int m = lane & 31, hh = lane >> 5;
+    float* gst = lds + IMG + wave * kGammaRow;           // wave-private gamma slab
+    const float* w1l = lds + kOffW1 + lane * 4;
+    const float* w2l = lds + kOffW2 + lane * 4;
+    const float* w3l = lds + kOffW3 + lane * 4;
+    const float* bl = lds + kOffB + 4 * hh;
+    const float* w4l = lds + kOffW4 + 4 * hh;
+    const float* gl = gst + 4 * hh;
+    const float b4 = lds[kOffB4];
+
+    const long long n_rows = p.n_end - p.n_begin;
+    const long long n_tiles = (n_rows + kTileM - 1) / kTileM;
+    const long long stride = (long long)gridDim.x * kWaves;
+    const int T = p.T;
+    const int draw0 = p.y_init ? (T - p.t_hi) : 0;       // first draw this call consumes
+    const int slot_base = p.y_init ? (T - p.t_hi) : 0;   // CARD_OUT_ALL: first state this call produces
+
+    for (long long tile = (long long)blockIdx.x * kWaves + wave; tile < n_tiles; tile += stride) {
+        const long long row = p.n_begin + tile * kTileM + m;
+        const bool valid = row < p.n_end;
+        const long long rc = valid ? row : p.n_end - 1;
+        const float mu = p.ytmean[rc];
+        const float y0h = p.y0hat[rc];
+        const unsigned long long elem = p.elem_offset + (unsigned long long)rc;
+
+        // layer-1 input in B-operand order: k-step r takes feature 2r (lanes 0-31) and 2r+1 (lanes 32-63)
+        // of cat(y_t, y_0_hat, x) (regression/model.py:38-47); feature 0 (y_t) is rewritten every step.
+        float h0[K1 / 2];
+#pragma unroll
+        for (int r = 0; r < K1 / 2; ++r) {
+            const int k = 2 * r + hh;
+            float v = 0.0f;
+            if (k >= 1) {
+                if (p.cat_y_pred && k == 1) {
+                    v = y0h;
+                } else {
+                    const int xi = k - 1 - (p.cat_y_pred ? 1 : 0);
+                    if (p.cat_x && xi < p.x_dim) v = p.x[rc * p.x_dim + xi];
+                }
+            }
+            h0[r] = v;
+        }
+        const float s0 = h0[0];
+
+        float zc[4];
+        uint32_t zblock = 0xFFFFFFFFu;
+        auto draw = [&](int d) -> float {
+            if (p.noise) return p.noise[(long long)(d - draw0) * p.N + rc];
+            const uint32_t blk = (uint32_t)d >> 2;
+            if (blk != zblock) {
+                philox_normal4(p.seed, elem, blk, zc);
+                zblock = blk;
+            }
+            return pick4(zc, d & 3);
+        };
+        auto store_state = [&](int s, float v) {
+            long long slot;
+            if (p.out_mode == CARD_OUT_ALL) slot = s - slot_base;
+            else if (p.out_mode == CARD_OUT_SELECT) slot = p.state_slot[s];
+            else return;
+            if (slot >= 0 && valid && hh == 0) p.out[slot * p.N + row] = v;
+        };
+
+        float y;
+        if (p.y_init) {
+            y = p.y_init[rc];
+        } else {
+            y = draw(0) + mu;                                 // diffusion_utils.py:109-110
+            store_state(0, y);
+        }
+
+        // gamma row of the first step
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 6; ++i) gst[i * 64 + lane] = p.gtab[(long long)p.t_hi * kGammaRow + i * 64 + lane];
+        __builtin_amdgcn_wave_barrier();
+
+        for (int t = p.t_hi; t >= p.t_lo; --t) {
+            float gn[6];
+            const bool more = t > p.t_lo;
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) gn[i] = p.gtab[(long long)(t - 1) * kGammaRow + i * 64 + lane];
+            }
+            const float z = t >= 1 && !p.eps_only ? draw(T - t) : 0.0f;
+
+            h0[0] = hh == 0 ? y : s0;
+            f32x16 hA[4], hB[4];
+            layer_first<K1>(w1l, bl, gl, h0, hA);
+            layer_hidden(w2l, bl + kH, gl + kH, hA, hB);
+            layer_hidden(w3l, bl + 2 * kH, gl + 2 * kH, hB, hA);
+
+            // lin4: eps = W4 . h3 + b4 (regression/model.py:51), two half-wave partial sums
+            float part = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 w = lds4(w4l + 32 * j + 8 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) part = fmaf(hA[j][4 * q + e], w[e], part);
+                }
+            }
+            const float eps = (part + __shfl_xor(part, 32, 64)) + b4;
+
+            if (p.eps_only) {
+                if (valid && hh == 0) p.out[row] = eps;
+                break;
+            }
+
+            // posterior update, regression/diffusion_utils.py:83-89 (t >= 1) / :101-103 (t == 0)
+            const float* c = p.coef + (long long)t * CARD_COEF_COLS;
+            const float y0r = c[CARD_COEF_INV_SQRT_AB] * ((y - c[CARD_COEF_ONE_M_SQRT_AB] * mu) - eps * c[CARD_COEF_SOMAB]);
+            if (t >= 1) {
+                const float yh = (c[CARD_COEF_G0] * y0r + c[CARD_COEF_G1] * y) + c[CARD_COEF_G2] * mu;
+                y = yh + c[CARD_COEF_SIGMA] * z;
+            } else {
+                y = y0r;
+            }
+            store_state(T - t, y);
+
+            __builtin_amdgcn_wave_barrier();
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) gst[i * 64 + lane] = gn[i];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (p.out_mode == CARD_OUT_LAST && !p.eps_only && valid && hh == 0) p.out[row] = y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// create-time packing kernels
+// ------------------------------------------------------------------------------------------------
+// A-operand fragment order of a 128x128 layer: element e of lane l in block (j, jj, q) is
+// W[32j + (l&31)][32jj + 8q + 4(l>>5) + e] -- the k index a lane needs when the B operand is register
+// 4q+e of the previous layer's accumulator tile jj (C/D map: row = (reg&3) + 8(reg>>2) + 4(lane>>5)).
+__global__ void pack_hidden_kernel(const float* __restrict__ W, float scale, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= kH * kH) return;
+    const int e = idx & 3, l = (idx >> 2) & 63, q = (idx >> 8) & 3, jj = (idx >> 10) & 3, j = idx >> 12;
+    const int n = 32 * j + (l & 31), k = 32 * jj + 8 * q + 4 * (l >> 5) + e;
+    out[idx] = W[n * kH + k] * scale;
+}
+
+// layer 1: k-step r = 4q+e takes input feature 2r + (l>>5); columns >= d_in are zero padding
+__global__ void pack_first_kernel(const float* __restrict__ W1, int d_in, int K1, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= kH * K1) return;
+    const int nq = K1 / 8;
+    const int e = idx & 3, l = (idx >> 2) & 63, rest = idx >> 8, q = rest % nq, j = rest / nq;
+    const int n = 32 * j + (l & 31), k = 8 * q + 2 * e + (l >> 5);
+    out[idx] = k < d_in ? W1[n * d_in + k] : 0.0f;
+}
+
+__global__ void pack_misc_kernel(const float* b1, const float* b2, const float* b3, const float* W4,
+                                 const float* b4, float* __restrict__ img) {
+    const int i = threadIdx.x;  // 128 threads
+    img[kOffB + i] = b1[i];
+    img[kOffB + kH + i] = b2[i];
+    img[kOffB + 2 * kH + i] = b3[i];
+    img[kOffW4 + i] = W4[i] * kLn2;
+    if (i < 4) img[kOffB4 + i] = i == 0 ? b4[0] : 0.0f;
+}
+
+__global__ void pack_gamma_kernel(const float* g1, const float* g2, const float* g3, int n_embed,
+                                  float* __restrict__ gtab) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_embed * kGammaRow) return;
+    const int t = idx / kGammaRow, r = idx % kGammaRow, l = r / kH, n = r % kH;
+    const float* g = l == 0 ? g1 : (l == 1 ? g2 : g3);
+    gtab[idx] = g[t * kH + n] * kLog2e;
+}
+
+// ------------------------------------------------------------------------------------------------
+// q_sample and the RNG fill
+// ------------------------------------------------------------------------------------------------
+__global__ void q_sample_kernel(const float* __restrict__ y, const float* __restrict__ y0hat,
+                                const float* __restrict__ sab, const float* __restrict__ somab,
+                                const int64_t* __restrict__ t, long long n_elems, int y_dim,
+                                const float* __restrict__ noise, unsigned long long seed,
+                                unsigned long long elem_offset, float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_elems;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int64_t ti = t[i / y_dim];
+        const float a = sab[ti], s = somab[ti];
+        float e;
+        if (noise) {
+            e = noise[i];
+        } else {
+            float z[4];
+            philox_normal4(seed, elem_offset + (unsigned long long)i, 0u, z);
+            e = z[0];
+        }
+        // regression/diffusion_utils.py:52, left to right, no contraction
+        out[i] = (a * y[i] + (1.0f - a) * y0hat[i]) + s * e;
+    }
+}
+
+__global__ void philox_fill_kernel(unsigned long long seed, unsigned long long elem_offset, long long n_elems,
+                                   int draw0, int n_draws, float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_elems;
+         i += (long long)gridDim.x * blockDim.x) {
+        float z[4];
+        uint32_t blk = 0xFFFFFFFFu;
+        for (int k = 0; k < n_draws; ++k) {
+            const int d = draw0 + k;
+            if (((uint32_t)d >> 2) != blk) {
+                blk = (uint32_t)d >> 2;
+                philox_normal4(seed, elem_offset + (unsigned long long)i, blk, z);
+            }
+            out[(long long)k * n_elems + i] = pick4(z, d & 3);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(CARD_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+typedef void (*sample_kernel_t)(const RunParams);
+
+sample_kernel_t guided_kernel_for(int k1) {
+    switch (k1) {
+        case 8: return card_sample_guided_kernel<8>;
+        case 16: return card_sample_guided_kernel<16>;
+        case 24: return card_sample_guided_kernel<24>;
+        case 32: return card_sample_guided_kernel<32>;
+        default: return nullptr;
+    }
+}
+
+}  // namespace
+
+struct card_sampler {
+    int variant, x_dim, y_dim, hidden, n_embed, cat_x, cat_y_pred;
+    int d_in, k1;
+    int device, num_cu;
+    float* wpk;   // packed LDS image
+    float* gtab;  // (n_embed, 3, 128)
+    sample_kernel_t kernel;
+    size_t lds_bytes;
+};
+
+extern "C" CARD_API int card_version(void) { return CARD_HIP_VERSION; }
+extern "C" CARD_API const char* card_last_error(void) { return g_err; }
+
+extern "C" CARD_API int card_make_coef_table(const float* alphas, const float* omabs, int32_t T, float* out) {
+    if (!alphas || !omabs || !out || T < 1) return fail(CARD_E_INVALID, "card_make_coef_table: bad argument");
+    // regression/diffusion_utils.py:71-80, :88 in the same fp32 operation order (file built with
+    // -ffp-contract=off; sqrtf and / are correctly rounded, as torch's CPU kernels are)
+    for (int t = 0; t < T; ++t) {
+        float* r = out + (size_t)t * CARD_COEF_COLS;
+        const float s = omabs[t];
+        const float sab = sqrtf(1.0f - s * s);
+        r[CARD_COEF_INV_SQRT_AB] = 1.0f / sab;
+        r[CARD_COEF_ONE_M_SQRT_AB] = 1.0f - sab;
+        r[CARD_COEF_SOMAB] = s;
+        r[CARD_COEF_SQRT_AB] = sab;
+        r[CARD_COEF_G0] = r[CARD_COEF_G1] = r[CARD_COEF_G2] = r[CARD_COEF_SIGMA] = 0.0f;
+        if (t >= 1) {
+            const float a = alphas[t];
+            const float sm = omabs[t - 1];
+            const float sabm = sqrtf(1.0f - sm * sm);
+            const float s2 = s * s;
+            r[CARD_COEF_G0] = (1.0f - a) * sabm / s2;
+            r[CARD_COEF_G1] = (sm * sm) * sqrtf(a) / s2;
+            r[CARD_COEF_G2] = 1.0f + (sab - 1.0f) * (sqrtf(a) + sabm) / s2;
+            r[CARD_COEF_SIGMA] = sqrtf((sm * sm) / s2 * (1.0f - a));
+        }
+    }
+    return CARD_OK;
+}
+
+extern "C" CARD_API int card_sampler_create(const card_model_desc* d, void* stream_, card_sampler** out) {
+    if (!d || !out) return fail(CARD_E_INVALID, "card_sampler_create: null argument");
+    *out = nullptr;
+    if (d->struct_bytes != (int32_t)sizeof(card_model_desc))
+        return fail(CARD_E_INVALID, "card_sampler_create: struct_bytes %d != %zu", d->struct_bytes, sizeof(card_model_desc));
+    if (d->variant != CARD_VARIANT_GUIDED)
+        return fail(CARD_E_UNSUPPORTED, "card_sampler_create: variant %d not built yet", d->variant);
+    if (d->hidden != kH) return fail(CARD_E_UNSUPPORTED, "card_sampler_create: hidden=%d, only 128 is built", d->hidden);
+    if (d->y_dim != 1) return fail(CARD_E_UNSUPPORTED, "card_sampler_create: y_dim=%d, only 1 is built", d->y_dim);
+    if (d->n_embed < 1 || d->x_dim < 0) return fail(CARD_E_INVALID, "card_sampler_create: bad n_embed/x_dim");
+    for (int l = 0; l < 3; ++l)
+        if (!d->W[l] || !d->b[l] || !d->gamma[l]) return fail(CARD_E_INVALID, "card_sampler_create: null weight pointer (layer %d)", l + 1);
+    if (!d->W4 || !d->b4) return fail(CARD_E_INVALID, "card_sampler_create: null lin4 pointer");
+    const int d_in = d->y_dim + (d->cat_y_pred ? d->y_dim : 0) + (d->cat_x ? d->x_dim : 0);
+    const int k1 = (d_in + 7) / 8 * 8;
+    sample_kernel_t kern = guided_kernel_for(k1);
+    if (!kern) return fail(CARD_E_UNSUPPORTED, "card_sampler_create: d_in=%d (padded %d) exceeds the LDS-resident layer-1 limit of 32", d_in, k1);
+
+    hipStream_t stream = (hipStream_t)stream_;
+    card_sampler* s = new (std::nothrow) card_sampler();
+    if (!s) return fail(CARD_E_NOMEM, "card_sampler_create: out of host memory");
+    s->variant = d->variant; s->x_dim = d->x_dim; s->y_dim = d->y_dim; s->hidden = d->hidden;
+    s->n_embed = d->n_embed; s->cat_x = d->cat_x ? 1 : 0; s->cat_y_pred = d->cat_y_pred ? 1 : 0;
+    s->d_in = d_in; s->k1 = k1; s->kernel = kern; s->wpk = nullptr; s->gtab = nullptr;
+    const int img = img_floats(k1);
+    s->lds_bytes = (size_t)(img + kWaves * kGammaRow) * sizeof(float);
+    hipError_t e;
+    if ((e = hipGetDevice(&s->device)) != hipSuccess ||
+        (e = hipDeviceGetAttribute(&s->num_cu, hipDeviceAttributeMultiprocessorCount, s->device)) != hipSuccess ||
+        (e = hipMalloc(&s->wpk, (size_t)img * sizeof(float))) != hipSuccess ||
+        (e = hipMalloc(&s->gtab, (size_t)d->n_embed * kGammaRow * sizeof(float))) != hipSuccess ||
+        (e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes)) != hipSuccess) {
+        card_sampler_destroy(s);
+        return fail(CARD_E_HIP, "card_sampler_create: %s", hipGetErrorString(e));
+    }
+    pack_hidden_kernel<<<kH * kH / 256, 256, 0, stream>>>(d->W[1], kLn2, s->wpk + kOffW2);
+    pack_hidden_kernel<<<kH * kH / 256, 256, 0, stream>>>(d->W[2], kLn2, s->wpk + kOffW3);
+    pack_first_kernel<<<(kH * k1 + 255) / 256, 256, 0, stream>>>(d->W[0], d_in, k1, s->wpk + kOffW1);
+    pack_misc_kernel<<<1, kH, 0, stream>>>(d->b[0], d->b[1], d->b[2], d->W4, d->b4, s->wpk);
+    const int ng = d->n_embed * kGammaRow;
+    pack_gamma_kernel<<<(ng + 255) / 256, 256, 0, stream>>>(d->gamma[0], d->gamma[1], d->gamma[2], d->n_embed, s->gtab);
+    if ((e = hipGetLastError()) != hipSuccess) {
+        card_sampler_destroy(s);
+        return fail(CARD_E_HIP, "card_sampler_create: pack launch: %s", hipGetErrorString(e));
+    }
+    *out = s;
+    return CARD_OK;
+}
+
+extern "C" CARD_API void card_sampler_destroy(card_sampler* s) {
+    if (!s) return;
+    if (s->wpk) (void)hipFree(s->wpk);
+    if (s->gtab) (void)hipFree(s->gtab);
+    delete s;
+}
+
+namespace {
+
+int launch_sampler(const card_sampler* s, RunParams p, hipStream_t stream) {
+    // Split very large N into launches of whole waves-worth of tiles so that one launch stays well under
+    // a second and every wave gets the same number of tiles (no intra-launch tail except in the last one).
+    const long long waves = (long long)s->num_cu * kWaves;
+    const long long tiles_per_wave = 16;
+    const long long chunk = waves * tiles_per_wave * kTileM;
+    for (long long b = 0; b < p.N; b += chunk) {
+        p.n_begin = b;
+        p.n_end = b + chunk < p.N ? b + chunk : p.N;
+        const long long tiles = (p.n_end - p.n_begin + kTileM - 1) / kTileM;
+        long long grid = (tiles + kWaves - 1) / kWaves;
+        if (grid > s->num_cu) grid = s->num_cu;
+        s->kernel<<<dim3((unsigned)grid), dim3(kThreads), s->lds_bytes, stream>>>(p);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(CARD_E_HIP, "sampler launch: %s", hipGetErrorString(e));
+    }
+    return CARD_OK;
+}
+
+}  // namespace
+
+extern "C" CARD_API int card_sampler_run(const card_sampler* s, const card_run_args* a, void* stream) {
+    if (!s || !a) return fail(CARD_E_INVALID, "card_sampler_run: null argument");
+    if (a->struct_bytes != (int32_t)sizeof(card_run_args))
+        return fail(CARD_E_INVALID, "card_sampler_run: struct_bytes %d != %zu", a->struct_bytes, sizeof(card_run_args));
+    if (a->N < 0) return fail(CARD_E_INVALID, "card_sampler_run: N < 0");
+    if (a->T < 1 || a->T > s->n_embed)
+        return fail(CARD_E_INVALID, "card_sampler_run: T=%d outside [1, n_embed=%d]", a->T, s->n_embed);
+    if (a->t_lo < 0 || a->t_hi < a->t_lo || a->t_hi >= a->T)
+        return fail(CARD_E_INVALID, "card_sampler_run: need 0 <= t_lo <= t_hi < T (got %d, %d, T=%d)", a->t_lo, a->t_hi, a->T);
+    if (!a->y_init && a->t_hi != a->T - 1)
+        return fail(CARD_E_INVALID, "card_sampler_run: y_init == NULL starts a loop and needs t_hi == T-1");
+    if (!a->y_0_hat || !a->y_T_mean || !a->coef || !a->out)
+        return fail(CARD_E_INVALID, "card_sampler_run: null y_0_hat / y_T_mean / coef / out");
+    if (s->cat_x && s->x_dim > 0 && !a->x) return fail(CARD_E_INVALID, "card_sampler_run: x is NULL but the model concatenates x");
+    if (a->out_mode < CARD_OUT_LAST || a->out_mode > CARD_OUT_SELECT) return fail(CARD_E_INVALID, "card_sampler_run: bad out_mode");
+    if (a->out_mode == CARD_OUT_SELECT && !a->state_slot) return fail(CARD_E_INVALID, "card_sampler_run: CARD_OUT_SELECT needs state_slot");
+    if (a->N == 0) return CARD_OK;
+    RunParams p;
+    memset(&p, 0, sizeof(p));
+    p.wpk = s->wpk; p.gtab = s->gtab; p.coef = a->coef; p.x = a->x; p.y0hat = a->y_0_hat; p.ytmean = a->y_T_mean;
+    p.y_init = a->y_init; p.noise = a->noise; p.out = a->out; p.state_slot = a->state_slot;
+    p.N = a->N; p.seed = a->seed; p.elem_offset = a->elem_offset;
+    p.T = a->T; p.t_hi = a->t_hi; p.t_lo = a->t_lo;
+    p.x_dim = s->x_dim; p.cat_x = s->cat_x; p.cat_y_pred = s->cat_y_pred;
+    p.out_mode = a->out_mode; p.eps_only = 0;
+    return launch_sampler(s, p, (hipStream_t)stream);
+}
+
+extern "C" CARD_API int card_eps_theta(const card_sampler* s, const float* x, const float* y_t, const float* y_0_hat,
+                              int64_t N, int32_t t, float* out, void* stream) {
+    if (!s || !y_t || !y_0_hat || !out) return fail(CARD_E_INVALID, "card_eps_theta: null argument");
+    if (s->cat_x && s->x_dim > 0 && !x) return fail(CARD_E_INVALID, "card_eps_theta: x is NULL but the model concatenates x");
+    if (t < 0 || t >= s->n_embed) return fail(CARD_E_INVALID, "card_eps_theta: t=%d outside the gamma table", t);
+    if (N < 0) return fail(CARD_E_INVALID, "card_eps_theta: N < 0");
+    if (N == 0) return CARD_OK;
+    RunParams p;
+    memset(&p, 0, sizeof(p));
+    p.wpk = s->wpk; p.gtab = s->gtab; p.coef = nullptr; p.x = x; p.y0hat = y_0_hat; p.ytmean = y_0_hat;
+    p.y_init = y_t; p.noise = nullptr; p.out = out; p.N = N;
+    p.T = t + 1; p.t_hi = t; p.t_lo = t;
+    p.x_dim = s->x_dim; p.cat_x = s->cat_x; p.cat_y_pred = s->cat_y_pred;
+    p.out_mode = CARD_OUT_LAST; p.eps_only = 1;
+    return launch_sampler(s, p, (hipStream_t)stream);
+}
+
+extern "C" CARD_API int card_q_sample(const float* y, const float* y_0_hat, const float* sab, const float* somab,
+                             const int64_t* t, int64_t N, int32_t y_dim, int32_t T, const float* noise, uint64_t seed,
+                             uint64_t elem_offset, float* out, void* stream) {
+    (void)T;
+    if (!y || !y_0_hat || !sab || !somab || !t || !out) return fail(CARD_E_INVALID, "card_q_sample: null argument");
+    if (N < 0 || y_dim < 1) return fail(CARD_E_INVALID, "card_q_sample: bad N / y_dim");
+    if (N == 0) return CARD_OK;
+    const long long n = (long long)N * y_dim;
+    long long grid = (n + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    q_sample_kernel<<<dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream>>>(y, y_0_hat, sab, somab, t, n, y_dim, noise, seed,
+                                                                                  elem_offset, out);
+    HIP_TRY(hipGetLastError());
+    return CARD_OK;
+}
+
+extern "C" CARD_API int card_philox_normal(uint64_t seed, uint64_t elem_offset, int64_t n_elems, int32_t draw0, int32_t n_draws,
+                                  float* out, void* stream) {
+    if (!out || n_elems < 0 || draw0 < 0 || n_draws < 0) return fail(CARD_E_INVALID, "card_philox_normal: bad argument");
+    if (n_elems == 0 || n_draws == 0) return CARD_OK;
+    long long grid = (n_elems + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    philox_fill_kernel<<<dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream>>>(seed, elem_offset, n_elems, draw0, n_draws, out);
+    HIP_TRY(hipGetLastError());
+    return CARD_OK;
+}

@@ -1,0 +1,148 @@
+"""Drop-in for the reference's `diffusion_utils` module on the sampling path.
+
+Same names, argument order and return types as /root/reference/regression/diffusion_utils.py (and the
+classification variant's extra `only_last_sample`), so `from diffusion_utils import *` callers
+(regression/card_regression.py:16) keep working unchanged; see INTEGRATION.md.  Extra keyword-only
+arguments (`noise`, `seed`, `elem_offset`, `states`) expose the kernel's validation / sharding modes.
+
+Everything here runs on the GPU through libcard_hip.so.  No fallback.
+"""
+import math
+
+import torch
+
+from . import _lib
+from ._lib import CardError
+from .sampler import coef_on_device, sampler_for, _dev_f32, _ptr, _stream, _require_cuda
+
+__all__ = ["make_beta_schedule", "extract", "q_sample", "p_sample", "p_sample_t_1to0", "p_sample_loop",
+           "y_0_reparam"]
+
+
+def make_beta_schedule(schedule="linear", num_timesteps=1000, start=1e-5, end=1e-2):
+    """Host-side schedule constructor, same contract as regression/diffusion_utils.py:6-31."""
+    if schedule == "linear":
+        betas = torch.linspace(start, end, num_timesteps)
+    elif schedule == "const":
+        betas = end * torch.ones(num_timesteps)
+    elif schedule == "quad":
+        betas = torch.linspace(start ** 0.5, end ** 0.5, num_timesteps) ** 2
+    elif schedule == "jsd":
+        betas = 1.0 / torch.linspace(num_timesteps, 1, num_timesteps)
+    elif schedule == "sigmoid":
+        betas = torch.sigmoid(torch.linspace(-6, 6, num_timesteps)) * (end - start) + start
+    elif schedule in ("cosine", "cosine_reverse"):
+        max_beta, s = 0.999, 0.008
+        f = lambda i: math.cos((i / num_timesteps + s) / (1 + s) * math.pi / 2) ** 2
+        betas = torch.tensor([min(1 - f(i + 1) / f(i), max_beta) for i in range(num_timesteps)])
+        if schedule == "cosine_reverse":
+            betas = betas.flip(0)
+    elif schedule == "cosine_anneal":
+        betas = torch.tensor([start + 0.5 * (end - start) * (1 - math.cos(t / (num_timesteps - 1) * math.pi))
+                              for t in range(num_timesteps)])
+    else:
+        raise ValueError(f"unknown beta schedule {schedule!r}")
+    return betas
+
+
+def extract(input, t, x):
+    """regression/diffusion_utils.py:34-38 (kept for callers that import it; not used by the kernels)."""
+    out = torch.gather(input, 0, t.to(input.device))
+    return out.reshape(*([t.shape[0]] + [1] * (len(x.shape) - 1)))
+
+
+def _fresh_seed():
+    # one draw from torch's global CPU generator: honours torch.manual_seed like the reference's randn_like
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+def q_sample(y, y_0_hat, alphas_bar_sqrt, one_minus_alphas_bar_sqrt, t, noise=None, *, seed=None, elem_offset=0):
+    """regression/diffusion_utils.py:42-53: y_t ~ q(y_t | y_0, x), per-row timestep tensor `t`."""
+    device = y.device
+    _require_cuda(device)
+    yy, y0 = _dev_f32(y, device), _dev_f32(y_0_hat, device)
+    if yy.dim() != 2 or y0.shape != yy.shape:
+        raise CardError(f"q_sample: y {tuple(y.shape)} and y_0_hat {tuple(y_0_hat.shape)} must both be (N, y_dim)")
+    sab, som = _dev_f32(alphas_bar_sqrt, device), _dev_f32(one_minus_alphas_bar_sqrt, device)
+    tt = t.detach().to(device=device, dtype=torch.int64).contiguous()
+    if tt.numel() != yy.shape[0]:
+        raise CardError("q_sample: t must have one entry per row of y")
+    nz = _dev_f32(noise, device) if noise is not None else None
+    if nz is not None and nz.shape != yy.shape:
+        raise CardError("q_sample: noise must have y's shape")
+    out = torch.empty_like(yy)
+    seed = _fresh_seed() if (seed is None and nz is None) else int(seed or 0)
+    with torch.cuda.device(device):
+        _lib.check(_lib.lib().card_q_sample(_ptr(yy), _ptr(y0), _ptr(sab), _ptr(som), _ptr(tt), yy.shape[0],
+                                            yy.shape[1], sab.numel(), _ptr(nz), seed, int(elem_offset), _ptr(out),
+                                            _stream(device)), "card_q_sample")
+    return out
+
+
+def p_sample(model, x, y, y_0_hat, y_T_mean, t, alphas, one_minus_alphas_bar_sqrt, *, noise=None, seed=None,
+             elem_offset=0):
+    """regression/diffusion_utils.py:57-90: one reverse step y_t -> y_{t-1}, t an int in [1, T-1]."""
+    s = sampler_for(model)
+    T = int(alphas.shape[0])
+    t = int(t)
+    if not 1 <= t < T:
+        raise CardError(f"p_sample: t={t} outside [1, {T - 1}]")
+    coef = coef_on_device(alphas, one_minus_alphas_bar_sqrt, T, s.device)
+    seed = _fresh_seed() if (seed is None and noise is None) else int(seed or 0)
+    return s.run(x, y_0_hat, y_T_mean, coef, T, t_hi=t, t_lo=t, y_init=y, noise=noise, seed=seed,
+                 elem_offset=elem_offset)
+
+
+def p_sample_t_1to0(model, x, y, y_0_hat, y_T_mean, one_minus_alphas_bar_sqrt):
+    """regression/diffusion_utils.py:94-104: the last step (timestep index 0), no noise."""
+    s = sampler_for(model)
+    T = int(one_minus_alphas_bar_sqrt.shape[0])
+    # only row 0 of the table is used and it depends on one_minus_alphas_bar_sqrt[0] alone
+    coef = coef_on_device(torch.ones_like(one_minus_alphas_bar_sqrt), one_minus_alphas_bar_sqrt, T, s.device) \
+        if False else _row0_coef(one_minus_alphas_bar_sqrt, s.device)
+    return s.run(x, y_0_hat, y_T_mean, coef, 1, t_hi=0, t_lo=0, y_init=y)
+
+
+def _row0_coef(omabs, device):
+    from .sampler import make_coef_table
+    one = torch.ones(1)
+    return make_coef_table(one, omabs.detach().to("cpu", torch.float32).reshape(-1)[:1], 1).to(device)
+
+
+def y_0_reparam(model, x, y, y_0_hat, y_T_mean, t, one_minus_alphas_bar_sqrt):
+    """classification/diffusion_utils.py:104-116: y_0 reparameterisation at a shared timestep tensor t (1,)."""
+    s = sampler_for(model)
+    ti = int(t.reshape(-1)[0].item()) if torch.is_tensor(t) else int(t)
+    som = one_minus_alphas_bar_sqrt.detach().to("cpu", torch.float32).reshape(-1)[ti:ti + 1]
+    from .sampler import make_coef_table
+    c = make_coef_table(torch.ones(1), som, 1)[0]
+    eps = s.eps_theta(x, y, y_0_hat, ti)
+    yy, mu = _dev_f32(y, s.device), _dev_f32(y_T_mean, s.device)
+    return float(c[_lib_col("INV")]) * (yy - float(c[_lib_col("OM")]) * mu - eps * float(c[_lib_col("SOMAB")]))
+
+
+def _lib_col(name):
+    return {"INV": 0, "OM": 1, "SOMAB": 2}[name]
+
+
+def p_sample_loop(model, x, y_0_hat, y_T_mean, n_steps, alphas, one_minus_alphas_bar_sqrt, only_last_sample=False,
+                  *, noise=None, seed=None, elem_offset=0, states=None):
+    """regression/diffusion_utils.py:107-119 (+ `only_last_sample`, classification/diffusion_utils.py:119-144).
+
+    Returns the reference's list of n_steps+1 tensors (index k <-> timestep n_steps-k; views of one
+    (n_steps+1, N, y_dim) buffer), or y_0 alone when only_last_sample.  `states=[...]` returns just those
+    list positions (stacked), `noise=(n_steps, N, y_dim)` injects the reference's randn stream, otherwise
+    noise comes from the in-kernel Philox generator keyed by `seed` (default: drawn from torch's RNG)."""
+    s = sampler_for(model)
+    T = int(n_steps)
+    coef = coef_on_device(alphas, one_minus_alphas_bar_sqrt, T, s.device)
+    seed = _fresh_seed() if (seed is None and noise is None) else int(seed or 0)
+    kw = dict(noise=noise, seed=seed, elem_offset=elem_offset)
+    if states is not None:
+        return s.run(x, y_0_hat, y_T_mean, coef, T, out_mode=_lib.OUT_SELECT, states=states, **kw)
+    if only_last_sample:
+        return s.run(x, y_0_hat, y_T_mean, coef, T, out_mode=_lib.OUT_LAST, **kw)
+    seq = s.run(x, y_0_hat, y_T_mean, coef, T, out_mode=_lib.OUT_ALL, **kw)
+    out = list(seq.unbind(0))
+    assert len(out) == T + 1
+    return out

@@ -1,0 +1,217 @@
+"""Host-side owner of a packed eps_theta network (card_sampler handle) and the run entry points."""
+import ctypes as C
+import weakref
+
+import torch
+
+from . import _lib
+from ._lib import CardError
+
+
+def _dev_f32(t, device):
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require_cuda(device):
+    if device.type != "cuda":
+        raise CardError(
+            f"card_amd runs on an AMD GPU only (model is on '{device}'); there is no CPU fallback. "
+            "Move the model and inputs to cuda.")
+
+
+def make_coef_table(alphas, one_minus_alphas_bar_sqrt, T=None):
+    """(T, 8) fp32 CPU tensor: card_make_coef_table (regression/diffusion_utils.py:71-80, :88)."""
+    a = alphas.detach().to("cpu", torch.float32).contiguous().reshape(-1)
+    s = one_minus_alphas_bar_sqrt.detach().to("cpu", torch.float32).contiguous().reshape(-1)
+    T = int(a.shape[0] if T is None else T)
+    if a.shape[0] < T or s.shape[0] < T:
+        raise CardError(f"alphas / one_minus_alphas_bar_sqrt have fewer than n_steps={T} entries")
+    out = torch.empty(T, _lib.COEF_COLS, dtype=torch.float32)
+    fp = C.POINTER(C.c_float)
+    _lib.check(_lib.lib().card_make_coef_table(C.cast(a.data_ptr(), fp), C.cast(s.data_ptr(), fp), T,
+                                               C.cast(out.data_ptr(), fp)), "card_make_coef_table")
+    return out
+
+
+_coef_cache = {}
+
+
+def coef_on_device(alphas, omabs, T, device):
+    key = (alphas.data_ptr(), alphas._version, omabs.data_ptr(), omabs._version, int(T), str(device))
+    hit = _coef_cache.get(key)
+    if hit is None:
+        if len(_coef_cache) > 16:
+            _coef_cache.clear()
+        hit = make_coef_table(alphas, omabs, T).to(device)
+        _coef_cache[key] = hit
+    return hit
+
+
+class Sampler:
+    """A packed eps_theta network on one GPU.  Immutable after construction."""
+
+    def __init__(self, *, variant, x_dim, y_dim, hidden, n_embed, cat_x, cat_y_pred, W, b, gamma, W4, b4,
+                 bn_scale=None, bn_shift=None, device):
+        device = torch.device(device)
+        _require_cuda(device)
+        L = _lib.lib()
+        self.device, self.variant = device, variant
+        self.x_dim, self.y_dim, self.hidden, self.n_embed = int(x_dim), int(y_dim), int(hidden), int(n_embed)
+        self.cat_x, self.cat_y_pred = bool(cat_x), bool(cat_y_pred)
+        keep = []
+
+        def dev(t):
+            t = _dev_f32(t, device)
+            keep.append(t)
+            return t
+
+        d = _lib.ModelDesc()
+        d.struct_bytes = C.sizeof(_lib.ModelDesc)
+        d.variant, d.x_dim, d.y_dim, d.hidden, d.n_embed = variant, self.x_dim, self.y_dim, self.hidden, self.n_embed
+        d.cat_x, d.cat_y_pred = int(self.cat_x), int(self.cat_y_pred)
+        for i in range(3):
+            d.W[i] = dev(W[i]).data_ptr()
+            d.b[i] = dev(b[i]).data_ptr()
+            d.gamma[i] = dev(gamma[i]).data_ptr()
+            if bn_scale is not None:
+                d.bn_scale[i] = dev(bn_scale[i]).data_ptr()
+                d.bn_shift[i] = dev(bn_shift[i]).data_ptr()
+        d.W4, d.b4 = dev(W4).data_ptr(), dev(b4).data_ptr()
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(L.card_sampler_create(C.byref(d), _stream(device), C.byref(h)), "card_sampler_create")
+            # the pack kernels read `keep` asynchronously on the current stream; the caching allocator is
+            # stream-ordered, so releasing them after this point is safe
+        self._h = h
+        self._destroy = L.card_sampler_destroy
+        weakref.finalize(self, L.card_sampler_destroy, h)
+
+    # ------------------------------------------------------------------------------------------
+    @classmethod
+    def from_state_dict(cls, sd, *, cat_x=True, cat_y_pred=True, device):
+        """Regression ConditionalGuidedModel weights (regression/model.py:21-35) from a state_dict."""
+        W1 = sd["lin1.lin.weight"]
+        y_dim = int(sd["lin4.weight"].shape[0])
+        d_in = int(W1.shape[1])
+        x_dim = d_in - y_dim - (y_dim if cat_y_pred else 0) if cat_x else 0
+        return cls(variant=_lib.VARIANT_GUIDED, x_dim=x_dim, y_dim=y_dim, hidden=int(W1.shape[0]),
+                   n_embed=int(sd["lin1.embed.weight"].shape[0]), cat_x=cat_x, cat_y_pred=cat_y_pred,
+                   W=[sd[f"lin{i}.lin.weight"] for i in (1, 2, 3)], b=[sd[f"lin{i}.lin.bias"] for i in (1, 2, 3)],
+                   gamma=[sd[f"lin{i}.embed.weight"] for i in (1, 2, 3)], W4=sd["lin4.weight"], b4=sd["lin4.bias"],
+                   device=device)
+
+    # ------------------------------------------------------------------------------------------
+    def _prep(self, t, cols, name):
+        if t is None:
+            return None
+        t = _dev_f32(t, self.device)
+        if t.dim() != 2 or t.shape[1] != cols:
+            raise CardError(f"{name}: expected shape (N, {cols}), got {tuple(t.shape)}")
+        return t
+
+    def run(self, x, y_0_hat, y_T_mean, coef, T, *, t_hi=None, t_lo=0, y_init=None, noise=None, seed=0,
+            elem_offset=0, out_mode=_lib.OUT_LAST, states=None):
+        """card_sampler_run.  Returns (N, y_dim) for OUT_LAST, (n_states, N, y_dim) otherwise."""
+        T = int(T)
+        t_hi = T - 1 if t_hi is None else int(t_hi)
+        t_lo = int(t_lo)
+        y0 = self._prep(y_0_hat, self.y_dim, "y_0_hat")
+        mu = self._prep(y_T_mean, self.y_dim, "y_T_mean")
+        N = int(y0.shape[0])
+        need_x = self.variant != _lib.VARIANT_GUIDED or (self.cat_x and self.x_dim > 0)
+        xx = self._prep(x, self.x_dim, "x") if need_x else None
+        yi = self._prep(y_init, self.y_dim, "y") if y_init is not None else None
+        for name, t in (("x", xx), ("y_T_mean", mu), ("y", yi)):
+            if t is not None and t.shape[0] != N:
+                raise CardError(f"{name} has {t.shape[0]} rows, y_0_hat has {N}")
+        n_steps = t_hi - t_lo + 1
+        n_states = n_steps + (0 if yi is not None else 1)
+        n_draws = (0 if yi is not None else 1) + (t_hi - max(t_lo, 1) + 1 if t_hi >= 1 else 0)
+        nz = None
+        if noise is not None:
+            nz = _dev_f32(noise, self.device)
+            if nz.numel() != n_draws * N * self.y_dim:
+                raise CardError(f"noise: expected {n_draws} x {N} x {self.y_dim} values, got {tuple(nz.shape)}")
+        slot = None
+        if out_mode == _lib.OUT_LAST:
+            out = torch.empty(N, self.y_dim, device=self.device, dtype=torch.float32)
+        elif out_mode == _lib.OUT_ALL:
+            out = torch.empty(n_states, N, self.y_dim, device=self.device, dtype=torch.float32)
+        else:
+            states = [int(s) for s in states]
+            table = torch.full((T + 1,), -1, dtype=torch.int32)
+            for i, s in enumerate(states):
+                if not 0 <= s <= T:
+                    raise CardError(f"state index {s} outside [0, {T}]")
+                table[s] = i
+            slot = table.to(self.device)
+            out = torch.empty(len(states), N, self.y_dim, device=self.device, dtype=torch.float32)
+        a = _lib.RunArgs()
+        a.struct_bytes = C.sizeof(_lib.RunArgs)
+        a.T, a.t_hi, a.t_lo, a.N = T, t_hi, t_lo, N
+        a.x, a.y_0_hat, a.y_T_mean, a.y_init = _ptr(xx), _ptr(y0), _ptr(mu), _ptr(yi)
+        a.coef, a.noise = _ptr(coef), _ptr(nz)
+        a.seed, a.elem_offset = int(seed) & (2 ** 64 - 1), int(elem_offset)
+        a.out, a.out_mode, a.state_slot = _ptr(out), out_mode, _ptr(slot)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().card_sampler_run(self._h, C.byref(a), _stream(self.device)), "card_sampler_run")
+        return out
+
+    def eps_theta(self, x, y_t, y_0_hat, t):
+        """model(x, y_t, y_0_hat, t) of the packed network: card_eps_theta."""
+        y0 = self._prep(y_0_hat, self.y_dim, "y_0_hat")
+        yt = self._prep(y_t, self.y_dim, "y_t")
+        need_x = self.variant != _lib.VARIANT_GUIDED or (self.cat_x and self.x_dim > 0)
+        xx = self._prep(x, self.x_dim, "x") if need_x else None
+        N = int(y0.shape[0])
+        out = torch.empty(N, self.y_dim, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().card_eps_theta(self._h, _ptr(xx), _ptr(yt), _ptr(y0), N, int(t), _ptr(out),
+                                                 _stream(self.device)), "card_eps_theta")
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+# model -> Sampler, cached per model object and invalidated when any parameter is modified in place
+# (the reference copies the EMA shadow into the parameters before testing: regression/card_regression.py:934-940)
+# ------------------------------------------------------------------------------------------------
+_cache = weakref.WeakKeyDictionary()
+
+
+def _fingerprint(model):
+    return tuple((p.data_ptr(), p._version, str(p.device)) for p in model.state_dict().values())
+
+
+def _is_guided(model):
+    # regression/model.py:21 ConditionalGuidedModel, recognised by structure (duck-typed `model` contract)
+    return all(hasattr(model, n) for n in ("lin1", "lin2", "lin3", "lin4", "cat_x", "cat_y_pred")) and \
+        hasattr(model.lin1, "lin") and hasattr(model.lin1, "embed") and not hasattr(model, "unetnorm1")
+
+
+def sampler_for(model):
+    """The cached Sampler of an eps_theta `nn.Module` (raises for architectures the kernels do not cover)."""
+    if getattr(model, "training", False):
+        raise CardError("card_amd samples in eval mode only (call model.eval(); the reference tests under "
+                        "model.eval() + torch.no_grad(), regression/card_regression.py:944, :1006)")
+    fp = _fingerprint(model)
+    hit = _cache.get(model)
+    if hit is not None and hit[0] == fp:
+        return hit[1]
+    device = next(model.parameters()).device
+    _require_cuda(device)
+    if _is_guided(model):
+        s = Sampler.from_state_dict(model.state_dict(), cat_x=bool(model.cat_x), cat_y_pred=bool(model.cat_y_pred),
+                                    device=device)
+    else:
+        raise CardError(f"card_amd does not recognise {type(model).__name__} as a CARD eps_theta network "
+                        "(expected regression ConditionalGuidedModel); there is no eager fallback")
+    _cache[model] = (fp, s)
+    return s

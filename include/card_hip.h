@@ -1,0 +1,157 @@
+/*
+ * card_hip.h - C ABI of libcard_hip.so: CARD's reverse-diffusion sampling path on MI355X (gfx950).
+ *
+ * The reference (XzwHan/CARD) is pure Python; it has no FFI of its own.  The "plugin" boundary for
+ * this path is the set of module-level functions in its tree-local `diffusion_utils` module
+ * (star-imported by the runners: regression/card_regression.py:16, classification/card_classification.py:19).
+ * Each entry point below names the reference function it stands in for; `card_amd/diffusion_utils.py`
+ * is the Python binding a maintainer drops in.
+ *
+ * Conventions
+ *   - every pointer called "device" is a HIP device pointer on the current device; fp32, row-major, contiguous
+ *   - every call is stream-ordered on `stream` (a hipStream_t passed as void*; NULL = default stream) and
+ *     never synchronises the device
+ *   - return value: 0 = ok, negative = card_status; card_last_error() gives a thread-local message
+ *   - a created sampler is immutable: concurrent card_sampler_run calls on different streams are safe
+ *   - timestep index t runs T-1 ... 0 exactly like the reference's `reversed(range(1, n_steps))` + t = 0;
+ *     "state index" s = T - t (s = 0 is y_T, s = T is y_0), i.e. position in the reference's y_p_seq list
+ */
+#ifndef CARD_HIP_H
+#define CARD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CARD_HIP_VERSION 100 /* major*10000 + minor*100 + patch */
+#define CARD_API __attribute__((visibility("default")))
+
+typedef enum card_status {
+    CARD_OK = 0,
+    CARD_E_INVALID = -1,     /* bad argument (null pointer, negative size, t out of range ...) */
+    CARD_E_UNSUPPORTED = -2, /* shape outside what the kernels are built for */
+    CARD_E_HIP = -3,         /* a HIP runtime call failed (message has hipGetErrorString) */
+    CARD_E_NOMEM = -4
+} card_status;
+
+typedef enum card_variant {
+    /* regression/model.py:21-51 ConditionalGuidedModel: cat(y_t, y_0_hat, x) -> 3 x (Linear, *gamma[t], softplus) -> Linear */
+    CARD_VARIANT_GUIDED = 0,
+    /* classification/model.py:22-94 ConditionalModel after the hoisted encoder: eval-BatchNorm after each
+       ConditionalLinear and a Hadamard product with x_feat = norm(encoder_x(x)) after layer 1 */
+    CARD_VARIANT_BN_HADAMARD = 1
+} card_variant;
+
+typedef enum card_out_mode {
+    CARD_OUT_LAST = 0,  /* out is (N, y_dim): the last state the call produces (y_0 when t_lo == 0) */
+    CARD_OUT_ALL = 1,   /* out is (n_states, N, y_dim): every state the call produces, in order */
+    CARD_OUT_SELECT = 2 /* out is (n_slots, N, y_dim): state s goes to slot state_slot[s], skipped when < 0 */
+} card_out_mode;
+
+/* Columns of one row of the (T, 8) coefficient table (card_make_coef_table). */
+enum {
+    CARD_COEF_INV_SQRT_AB = 0,
+    CARD_COEF_ONE_M_SQRT_AB = 1,
+    CARD_COEF_SOMAB = 2,
+    CARD_COEF_G0 = 3,
+    CARD_COEF_G1 = 4,
+    CARD_COEF_G2 = 5,
+    CARD_COEF_SIGMA = 6,
+    CARD_COEF_SQRT_AB = 7,
+    CARD_COEF_COLS = 8
+};
+
+/* Weights of the eps_theta network, exactly as the reference's state_dict holds them
+ * (lin{1,2,3}.lin.weight (H,in), .lin.bias (H,), lin{1,2,3}.embed.weight (T+1,H),
+ * lin4.weight (y_dim,H), lin4.bias (y_dim,)).  All device pointers; they are copied/packed at create time. */
+typedef struct card_model_desc {
+    int32_t struct_bytes; /* sizeof(card_model_desc), for forward compatibility */
+    int32_t variant;      /* card_variant */
+    int32_t x_dim;        /* GUIDED: columns of x (used when cat_x);  BN_HADAMARD: must equal hidden */
+    int32_t y_dim;        /* 1 for regression, number of classes for classification */
+    int32_t hidden;       /* H (128 for every reference regression model, regression/model.py:32-35) */
+    int32_t n_embed;      /* rows of the gamma tables (= timesteps + 1, regression/model.py:24) */
+    int32_t cat_x;        /* regression/model.py:25, GUIDED only */
+    int32_t cat_y_pred;   /* regression/model.py:26; BN_HADAMARD: `guidance` (classification/model.py:31) */
+    const float* W[3];    /* lin{1,2,3}.lin.weight */
+    const float* b[3];    /* lin{1,2,3}.lin.bias */
+    const float* gamma[3];/* lin{1,2,3}.embed.weight */
+    const float* W4;      /* lin4.weight */
+    const float* b4;      /* lin4.bias */
+    const float* bn_scale[3]; /* BN_HADAMARD: weight / sqrt(running_var + eps) of unetnorm{1,2,3}; else NULL */
+    const float* bn_shift[3]; /* BN_HADAMARD: bias - running_mean * scale; else NULL */
+} card_model_desc;
+
+typedef struct card_sampler card_sampler;
+
+/* Library version (CARD_HIP_VERSION of the build). */
+CARD_API int card_version(void);
+
+/* Message of the last failing call on this thread ("" if none). */
+CARD_API const char* card_last_error(void);
+
+/* Host-side, no GPU: the per-timestep scalars p_sample derives from t
+ * (regression/diffusion_utils.py:71-80, :88; p_sample_t_1to0 :97-98), same fp32 operation order.
+ * alphas, one_minus_alphas_bar_sqrt: host arrays of T floats.  out: host array of T*8 floats. */
+CARD_API int card_make_coef_table(const float* alphas, const float* one_minus_alphas_bar_sqrt, int32_t T, float* out);
+
+/* Pack the weights of one eps_theta network into the kernel's LDS image and per-timestep gamma table.
+ * Replaces: the `model` argument of p_sample / p_sample_loop (regression/diffusion_utils.py:57, :107). */
+CARD_API int card_sampler_create(const card_model_desc* desc, void* stream, card_sampler** out);
+CARD_API void card_sampler_destroy(card_sampler* s);
+
+/* Arguments of one sampling call. */
+typedef struct card_run_args {
+    int32_t struct_bytes;   /* sizeof(card_run_args) */
+    int32_t T;              /* n_steps of the reference loop; rows of coef */
+    int32_t t_hi;           /* first timestep index processed (T-1 for a full loop) */
+    int32_t t_lo;           /* last timestep index processed (0 for a full loop; 0 runs p_sample_t_1to0) */
+    int64_t N;              /* rows = test rows x z-samples, flattened (row, z) */
+    const float* x;         /* device (N, x_dim): GUIDED x (may be NULL when !cat_x); BN_HADAMARD x_feat (N, H) */
+    const float* y_0_hat;   /* device (N, y_dim) */
+    const float* y_T_mean;  /* device (N, y_dim) */
+    const float* y_init;    /* device (N, y_dim) state at timestep t_hi+... : y_t fed to the first step.
+                               NULL = start of a loop: y_T = noise draw 0 + y_T_mean (diffusion_utils.py:109-110);
+                               requires t_hi == T-1 */
+    const float* coef;      /* device (T, 8) from card_make_coef_table */
+    const float* noise;     /* device (n_draws, N, y_dim) injected N(0,1) draws in consumption order, or NULL
+                               for the in-kernel Philox4x32-10 generator.  n_draws = (y_init ? 0 : 1) +
+                               number of processed timesteps with t >= 1 */
+    uint64_t seed;          /* Philox key (noise == NULL) */
+    uint64_t elem_offset;   /* global index of element (0,0) of this call: keeps RNG streams independent of
+                               how rows are sharded over GPUs / calls */
+    float* out;             /* device, see card_out_mode */
+    int32_t out_mode;
+    const int32_t* state_slot; /* device (T+1) ints, CARD_OUT_SELECT only */
+} card_run_args;
+
+/* Run timesteps t_hi ... t_lo of the reverse process for N independent chains in ONE persistent kernel.
+ * Replaces: p_sample_loop (regression/diffusion_utils.py:107-119, classification/diffusion_utils.py:119-144)
+ * with y_init == NULL, t_hi = T-1, t_lo = 0;  p_sample (:57-90) with t_hi = t_lo = t >= 1;
+ * p_sample_t_1to0 (:94-104) with t_hi = t_lo = 0. */
+CARD_API int card_sampler_run(const card_sampler* s, const card_run_args* args, void* stream);
+
+/* eps_theta forward only: out (N, y_dim) = model(x, y_t, y_0_hat, t).
+ * Replaces: ConditionalGuidedModel.forward (regression/model.py:37-51) /
+ * ConditionalModel.forward after the encoder (classification/model.py:82-94). */
+CARD_API int card_eps_theta(const card_sampler* s, const float* x, const float* y_t, const float* y_0_hat, int64_t N,
+                   int32_t t, float* out, void* stream);
+
+/* Forward process sample, regression/diffusion_utils.py:42-53:
+ * out = sqrt_ab[t_i]*y + (1 - sqrt_ab[t_i])*y_0_hat + somab[t_i]*noise, per-row t (device int64 (N,)).
+ * noise: device (N, y_dim) or NULL for Philox (seed, elem_offset). */
+CARD_API int card_q_sample(const float* y, const float* y_0_hat, const float* alphas_bar_sqrt,
+                  const float* one_minus_alphas_bar_sqrt, const int64_t* t, int64_t N, int32_t y_dim, int32_t T,
+                  const float* noise, uint64_t seed, uint64_t elem_offset, float* out, void* stream);
+
+/* Fill out (n_draws, N, y_dim) with exactly the normals the sampler draws in RNG mode (draw d0 + i in slab i).
+ * No reference counterpart (the reference uses torch.randn_like); used to check RNG mode against injected mode. */
+CARD_API int card_philox_normal(uint64_t seed, uint64_t elem_offset, int64_t n_elems, int32_t draw0, int32_t n_draws,
+                       float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CARD_HIP_H */

@@ -319,9 +319,10 @@ def philox_normal(seed: int, elem_index: np.ndarray, draw: int) -> np.ndarray:
                     np.full(e.shape, draw >> 2, dtype=np.uint32), np.zeros(e.shape, dtype=np.uint32)], axis=-1)
     r = philox4x32_10(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))
     pair, which = (draw & 3) >> 1, draw & 1
-    u1 = ((r[..., 2 * pair] >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -24)
-    u2 = ((r[..., 2 * pair + 1] >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -24)
-    rad = np.sqrt(np.float32(-2.0) * np.log(u1.astype(np.float64))).astype(np.float32)
+    # 23 random bits + 0.5 is exact in fp32 and lies strictly inside (0, 1)
+    u1 = ((r[..., 2 * pair] >> np.uint32(9)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -23)
+    u2 = ((r[..., 2 * pair + 1] >> np.uint32(9)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -23)
+    rad = np.sqrt(-2.0 * np.log(u1.astype(np.float64))).astype(np.float32)
     ang = 2.0 * np.pi * u2.astype(np.float64)
     trig = np.sin(ang) if which else np.cos(ang)
     return (rad * trig.astype(np.float32)).astype(np.float32)
