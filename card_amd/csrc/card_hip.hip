@@ -569,12 +569,12 @@ extern "C" CARD_API int card_sampler_run(const card_sampler* s, const card_run_a
         return fail(CARD_E_INVALID, "card_sampler_run: need 0 <= t_lo <= t_hi < T (got %d, %d, T=%d)", a->t_lo, a->t_hi, a->T);
     if (!a->y_init && a->t_hi != a->T - 1)
         return fail(CARD_E_INVALID, "card_sampler_run: y_init == NULL starts a loop and needs t_hi == T-1");
+    if (a->N == 0) return CARD_OK;  // empty batch: nothing to read or write
     if (!a->y_0_hat || !a->y_T_mean || !a->coef || !a->out)
         return fail(CARD_E_INVALID, "card_sampler_run: null y_0_hat / y_T_mean / coef / out");
     if (s->cat_x && s->x_dim > 0 && !a->x) return fail(CARD_E_INVALID, "card_sampler_run: x is NULL but the model concatenates x");
     if (a->out_mode < CARD_OUT_LAST || a->out_mode > CARD_OUT_SELECT) return fail(CARD_E_INVALID, "card_sampler_run: bad out_mode");
     if (a->out_mode == CARD_OUT_SELECT && !a->state_slot) return fail(CARD_E_INVALID, "card_sampler_run: CARD_OUT_SELECT needs state_slot");
-    if (a->N == 0) return CARD_OK;
     RunParams p;
     memset(&p, 0, sizeof(p));
     p.wpk = s->wpk; p.gtab = s->gtab; p.coef = a->coef; p.x = a->x; p.y0hat = a->y_0_hat; p.ytmean = a->y_T_mean;

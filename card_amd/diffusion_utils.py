@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from ._lib import CardError
-from .sampler import coef_on_device, sampler_for, _dev_f32, _ptr, _stream, _require_cuda
+from .sampler import coef_on_device, make_coef_table, sampler_for, _dev_f32, _ptr, _stream, _require_cuda
 
 __all__ = ["make_beta_schedule", "extract", "q_sample", "p_sample", "p_sample_t_1to0", "p_sample_loop",
            "y_0_reparam"]
@@ -93,36 +93,28 @@ def p_sample(model, x, y, y_0_hat, y_T_mean, t, alphas, one_minus_alphas_bar_sqr
                  elem_offset=elem_offset)
 
 
+def _coef_row(one_minus_alphas_bar_sqrt, ti):
+    """Row `ti` of the coefficient table restricted to what p_sample_t_1to0 / y_0_reparam need (columns
+    0-2 depend on one_minus_alphas_bar_sqrt[ti] alone), as a (1, 8) CPU tensor."""
+    som = one_minus_alphas_bar_sqrt.detach().to("cpu", torch.float32).reshape(-1)[ti:ti + 1]
+    return make_coef_table(torch.ones(1), som, 1)
+
+
 def p_sample_t_1to0(model, x, y, y_0_hat, y_T_mean, one_minus_alphas_bar_sqrt):
     """regression/diffusion_utils.py:94-104: the last step (timestep index 0), no noise."""
     s = sampler_for(model)
-    T = int(one_minus_alphas_bar_sqrt.shape[0])
-    # only row 0 of the table is used and it depends on one_minus_alphas_bar_sqrt[0] alone
-    coef = coef_on_device(torch.ones_like(one_minus_alphas_bar_sqrt), one_minus_alphas_bar_sqrt, T, s.device) \
-        if False else _row0_coef(one_minus_alphas_bar_sqrt, s.device)
+    coef = _coef_row(one_minus_alphas_bar_sqrt, 0).to(s.device)
     return s.run(x, y_0_hat, y_T_mean, coef, 1, t_hi=0, t_lo=0, y_init=y)
-
-
-def _row0_coef(omabs, device):
-    from .sampler import make_coef_table
-    one = torch.ones(1)
-    return make_coef_table(one, omabs.detach().to("cpu", torch.float32).reshape(-1)[:1], 1).to(device)
 
 
 def y_0_reparam(model, x, y, y_0_hat, y_T_mean, t, one_minus_alphas_bar_sqrt):
     """classification/diffusion_utils.py:104-116: y_0 reparameterisation at a shared timestep tensor t (1,)."""
     s = sampler_for(model)
     ti = int(t.reshape(-1)[0].item()) if torch.is_tensor(t) else int(t)
-    som = one_minus_alphas_bar_sqrt.detach().to("cpu", torch.float32).reshape(-1)[ti:ti + 1]
-    from .sampler import make_coef_table
-    c = make_coef_table(torch.ones(1), som, 1)[0]
+    c = _coef_row(one_minus_alphas_bar_sqrt, ti)[0]
     eps = s.eps_theta(x, y, y_0_hat, ti)
     yy, mu = _dev_f32(y, s.device), _dev_f32(y_T_mean, s.device)
-    return float(c[_lib_col("INV")]) * (yy - float(c[_lib_col("OM")]) * mu - eps * float(c[_lib_col("SOMAB")]))
-
-
-def _lib_col(name):
-    return {"INV": 0, "OM": 1, "SOMAB": 2}[name]
+    return float(c[0]) * (yy - float(c[1]) * mu - eps * float(c[2]))
 
 
 def p_sample_loop(model, x, y_0_hat, y_T_mean, n_steps, alphas, one_minus_alphas_bar_sqrt, only_last_sample=False,

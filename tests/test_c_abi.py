@@ -1,0 +1,79 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/card_hip.h declares,
+and its host-only entry point (coefficient table) matches the oracle.  No GPU compute here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from card_amd import _lib
+from card_amd.sampler import make_coef_table
+from oracle import card_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "card_hip.h")).read()
+    return re.findall(r"CARD_API\s+[\w\s\*]+?\b(card_\w+)\s*\(", text)
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    names = declared_symbols()
+    assert len(names) >= 9 and set(names) == set(_lib.EXPORTS)
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), n
+    assert _lib.lib().card_version() == 100
+
+
+def test_struct_sizes_match_header_layout():
+    # 8 int32 + 17 pointers; 4 int32 + int64 + 6 ptr + 2 u64 + ptr + int32(+pad) + ptr
+    assert ctypes.sizeof(_lib.ModelDesc) == 8 * 4 + 17 * 8
+    assert ctypes.sizeof(_lib.RunArgs) == 16 + 8 + 6 * 8 + 16 + 8 + 8 + 8
+
+
+def test_error_reporting_without_gpu():
+    L = _lib.lib()
+    assert L.card_make_coef_table(None, None, 0, None) == -1
+    assert b"card_make_coef_table" in L.card_last_error()
+    with pytest.raises(_lib.CardError):
+        _lib.check(-1, "x")
+
+
+@pytest.mark.parametrize("sched", [("linear", 1000, 1e-4, 0.02), ("linear", 50, 1e-4, 0.4), ("cosine", 100, 1e-4, 0.02),
+                                   ("quad", 100, 1e-4, 0.02), ("sigmoid", 100, 1e-4, 0.02), ("const", 20, 1e-4, 0.02)])
+def test_coef_table_matches_ieee_restatement_and_oracle(sched):
+    alphas, _, omabs = orc.make_schedule(*sched)
+    got = make_coef_table(alphas, omabs).numpy()
+    # (a) bit-exact against an IEEE fp32 numpy restatement of regression/diffusion_utils.py:71-80, :88
+    f = np.float32
+    a, s = alphas.numpy(), omabs.numpy()
+    sab = np.sqrt(f(1) - s * s)
+    want = np.zeros_like(got)
+    want[:, 0], want[:, 1], want[:, 2], want[:, 7] = f(1) / sab, f(1) - sab, s, sab
+    s2, sm, sabm, at = s[1:] * s[1:], s[:-1], sab[:-1], a[1:]
+    want[1:, 3] = (f(1) - at) * sabm / s2
+    want[1:, 4] = (sm * sm) * np.sqrt(at) / s2
+    want[1:, 5] = f(1) + (sab[1:] - f(1)) * (np.sqrt(at) + sabm) / s2
+    want[1:, 6] = np.sqrt((sm * sm) / s2 * (f(1) - at))
+    assert np.array_equal(got, want)
+    # (b) against the oracle's torch table: torch's vectorised CPU sqrt is not correctly rounded (about
+    # 0.6 % of inputs are 1 ulp off), so the two agree to an ulp of the sqrt; gamma_2 = 1 + (...) amplifies
+    # that by its cancellation, hence the absolute bound there
+    ref = orc.make_coef_table(alphas, omabs).numpy()
+    for c in (0, 1, 2, 3, 4, 6, 7):
+        np.testing.assert_allclose(got[:, c], ref[:, c], rtol=4e-7, atol=2e-7)
+    np.testing.assert_allclose(got[:, 5], ref[:, 5], rtol=0, atol=1e-6)
+
+
+def test_no_gpu_fails_loudly():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import card_amd
+    m = torch.nn.Linear(2, 2)
+    with pytest.raises(_lib.CardError):
+        card_amd.p_sample_loop(m.eval(), torch.zeros(1, 1), torch.zeros(1, 1), torch.zeros(1, 1), 10,
+                               torch.ones(10), torch.ones(10))
