@@ -162,7 +162,9 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get("rows") == a.rows and tj.get("nz") == a.nz and tj.get("x_dim") == x_dim and tj.get("T") == T:
+            # measured for ONE full-size launch of the same shape (tools/profile_pmc.sh); valid when this run's
+            # launches are that size too
+            if tj.get("x_dim") == x_dim and tj.get("T") == T and tj.get("rows_per_launch") == chunk and N >= chunk:
                 traffic = tj.get("hbm_bytes_per_launch")
         out = {
             "metric": "reverse-diffusion sample-steps/sec (p_sample_loop)",
