@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcard_hip.so")
+LIB_PATH = os.environ.get("CARD_AMD_LIB") or os.path.join(_HERE, "libcard_hip.so")  # override: kernel A/B builds
 
 CARD_OK = 0
 VARIANT_GUIDED, VARIANT_BN_HADAMARD = 0, 1

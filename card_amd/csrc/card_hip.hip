@@ -21,6 +21,7 @@
 #include <string.h>
 #include <stdarg.h>
 #include <math.h>
+#include <stdlib.h>
 #include <new>
 
 #include "card_hip.h"
@@ -44,7 +45,8 @@ constexpr int kOffW3 = kH * kH;           // 128x128 in fragment order
 constexpr int kOffB = 2 * kH * kH;        // b1 | b2 | b3
 constexpr int kOffW4 = kOffB + 3 * kH;    // W4 * ln2
 constexpr int kOffB4 = kOffW4 + kH;       // b4 (+3 pad)
-constexpr int kOffW1 = kOffB4 + 4;        // 128 x K1 in fragment order
+constexpr int kOffW1 = kOffB4 + 4;        // 128 x K1 in fragment order; HOIST kernels: column 0 of W1 (k1 = 1)
+constexpr int kSlotFloats = kTileM * kH;  // one wave's hoisted layer-1 tile (32 chains x 128 features)
 __host__ __device__ constexpr int img_floats(int k1) { return kOffW1 + kH * k1; }
 constexpr int kGammaRow = 3 * kH;         // one timestep's gamma*log2e for the 3 layers
 
@@ -68,6 +70,10 @@ struct RunParams {
     int x_dim, cat_x, cat_y_pred;
     int out_mode;
     int eps_only;         // write eps_theta(y_init, t_hi) and stop
+    // hoisted layer 1 (HOIST kernels): static columns of W1 in fragment order + per-wave scratch slots
+    const float* w1s;     // (4, nqs, 64, 4): W1[32j + (l&31)][1 + 8q + 2e + (l>>5)]
+    float* ws;            // grid * 8 waves * 4096 floats
+    int nqs;              // ceil((d_in - 1) / 8)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -116,6 +122,24 @@ __device__ __forceinline__ float softplus_l2(float xs) {
 
 __device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+// gamma multiply + softplus of one 32-feature x 32-chain accumulator tile, in place
+__device__ __forceinline__ void epilogue_tile(f32x16& acc, const float* gl, int j) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 g = lds4(gl + 32 * j + 8 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * q + e] = softplus_l2(acc[4 * q + e] * g[e]);
+    }
+}
+
+__device__ __forceinline__ void load_bias(f32x16& acc, const float* bl, int j) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 b = lds4(bl + 32 * j + 8 * q);
+        acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
+    }
+}
+
 // One ConditionalLinear + softplus with a 128-wide input held in registers (hin = previous layer's
 // accumulators).  wl: packed weights, bl: bias, gl: this step's gamma*log2e (all LDS, pre-offset by lane).
 __device__ __forceinline__ void layer_hidden(const float* wl, const float* bl, const float* gl, const f32x16 (&hin)[4],
@@ -123,11 +147,7 @@ __device__ __forceinline__ void layer_hidden(const float* wl, const float* bl, c
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         f32x16 acc;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 b = lds4(bl + 32 * j + 8 * q);
-            acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
-        }
+        load_bias(acc, bl, j);
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
 #pragma unroll
@@ -138,12 +158,28 @@ __device__ __forceinline__ void layer_hidden(const float* wl, const float* bl, c
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], hin[jj][4 * q + e], acc, 0, 0, 0);
             }
         }
+        epilogue_tile(acc, gl, j);
+        hout[j] = acc;
+    }
+}
+
+// Layer 1 with the step-invariant part hoisted: the accumulator starts from this wave's scratch slot
+// c1 = b1 + W1[:, 1:] . (y_0_hat, x) (computed once per tile) and one K=2 MFMA per output tile adds
+// W1[:, 0] * y_t (a10: column 0 on lanes 0-31, zero on lanes 32-63; yb: y_t on lanes 0-31, zero above).
+__device__ __forceinline__ void layer_first_hoisted(const float* slot, const float (&a10)[4], float yb,
+                                                    const float* gl, f32x16 (&hout)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 g = lds4(gl + 32 * j + 8 * q);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) hout[j][4 * q + e] = softplus_l2(acc[4 * q + e] * g[e]);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(slot + (j * 4 + q) * 256);
+            hout[j][4 * q + 0] = c[0]; hout[j][4 * q + 1] = c[1]; hout[j][4 * q + 2] = c[2]; hout[j][4 * q + 3] = c[3];
         }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        hout[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a10[j], yb, hout[j], 0, 0, 0);
+        epilogue_tile(hout[j], gl, j);
     }
 }
 
@@ -154,11 +190,7 @@ __device__ __forceinline__ void layer_first(const float* wl, const float* bl, co
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         f32x16 acc;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 b = lds4(bl + 32 * j + 8 * q);
-            acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
-        }
+        load_bias(acc, bl, j);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const f32x4 a = lds4(wl + ((j * NQ + q) * 64) * 4);
@@ -166,22 +198,21 @@ __device__ __forceinline__ void layer_first(const float* wl, const float* bl, co
             for (int e = 0; e < 4; ++e)
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], h0[4 * q + e], acc, 0, 0, 0);
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 g = lds4(gl + 32 * j + 8 * q);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) hout[j][4 * q + e] = softplus_l2(acc[4 * q + e] * g[e]);
-        }
+        epilogue_tile(acc, gl, j);
+        hout[j] = acc;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// The persistent sampler kernel (CARD_VARIANT_GUIDED, y_dim = 1, H = 128, layer-1 K padded to K1).
+// The persistent sampler kernel (CARD_VARIANT_GUIDED, y_dim = 1, H = 128).
+//   HOIST = false: layer 1 runs on MFMA every step with W1 (K padded to K1 <= 32) resident in LDS.
+//   HOIST = true : any d_in; the step-invariant part of layer 1 is computed once per tile into the wave's
+//                  scratch slot (16 KB, re-read from L2 every step) and only W1[:,0]*y_t is added per step.
 // ------------------------------------------------------------------------------------------------
-template <int K1>
+template <int K1, bool HOIST>
 __global__ __launch_bounds__(kThreads, 2) void card_sample_guided_kernel(const RunParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int IMG = img_floats(K1);
+    constexpr int IMG = img_floats(HOIST ? 1 : K1);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -198,6 +229,13 @@ __global__ __launch_bounds__(kThreads, 2) void card_sample_guided_kernel(const R
     const float* w4l = lds + kOffW4 + 4 * hh;
     const float* gl = gst + 4 * hh;
     const float b4 = lds[kOffB4];
+    float a10[4] = {0.f, 0.f, 0.f, 0.f};
+    float* slot = nullptr;
+    if constexpr (HOIST) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a10[j] = hh == 0 ? lds[kOffW1 + 32 * j + m] : 0.0f;
+        slot = p.ws + ((long long)blockIdx.x * kWaves + wave) * kSlotFloats + lane * 4;
+    }
 
     const long long n_rows = p.n_end - p.n_begin;
     const long long n_tiles = (n_rows + kTileM - 1) / kTileM;
@@ -214,24 +252,48 @@ __global__ __launch_bounds__(kThreads, 2) void card_sample_guided_kernel(const R
         const float y0h = p.y0hat[rc];
         const unsigned long long elem = p.elem_offset + (unsigned long long)rc;
 
-        // layer-1 input in B-operand order: k-step r takes feature 2r (lanes 0-31) and 2r+1 (lanes 32-63)
-        // of cat(y_t, y_0_hat, x) (regression/model.py:38-47); feature 0 (y_t) is rewritten every step.
+        // feature k of cat(y_t, y_0_hat, x) (regression/model.py:38-47) for this lane's chain; k >= 1 is static
+        auto static_feature = [&](int k) -> float {
+            if (p.cat_y_pred && k == 1) return y0h;
+            const int xi = k - 1 - (p.cat_y_pred ? 1 : 0);
+            return (p.cat_x && xi < p.x_dim) ? p.x[rc * p.x_dim + xi] : 0.0f;
+        };
+        // layer-1 input in B-operand order: k-step r takes feature 2r (lanes 0-31) and 2r+1 (lanes 32-63);
+        // feature 0 (y_t) is rewritten every step.
         float h0[K1 / 2];
+        if constexpr (!HOIST) {
 #pragma unroll
-        for (int r = 0; r < K1 / 2; ++r) {
-            const int k = 2 * r + hh;
-            float v = 0.0f;
-            if (k >= 1) {
-                if (p.cat_y_pred && k == 1) {
-                    v = y0h;
-                } else {
-                    const int xi = k - 1 - (p.cat_y_pred ? 1 : 0);
-                    if (p.cat_x && xi < p.x_dim) v = p.x[rc * p.x_dim + xi];
+            for (int r = 0; r < K1 / 2; ++r) {
+                const int k = 2 * r + hh;
+                h0[r] = k >= 1 ? static_feature(k) : 0.0f;
+            }
+        } else {
+            // c1 = b1 + W1[:, 1:] . static features, once per tile, on MFMA with A fragments from global (L2)
+            f32x16 c[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) load_bias(c[j], bl, j);
+            for (int q = 0; q < p.nqs; ++q) {
+                float bq[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bq[e] = static_feature(1 + 8 * q + 2 * e + hh);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(p.w1s + ((long long)(j * p.nqs + q) * 64 + lane) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) c[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bq[e], c[j], 0, 0, 0);
                 }
             }
-            h0[r] = v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = {c[j][4 * q + 0], c[j][4 * q + 1], c[j][4 * q + 2], c[j][4 * q + 3]};
+                    *reinterpret_cast<f32x4*>(slot + (j * 4 + q) * 256) = v;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        const float s0 = h0[0];
+        const float s0 = HOIST ? 0.0f : h0[0];
 
         float zc[4];
         uint32_t zblock = 0xFFFFFFFFu;
@@ -275,13 +337,17 @@ __global__ __launch_bounds__(kThreads, 2) void card_sample_guided_kernel(const R
             }
             const float z = t >= 1 && !p.eps_only ? draw(T - t) : 0.0f;
 
-            h0[0] = hh == 0 ? y : s0;
             f32x16 hA[4], hB[4];
-            layer_first<K1>(w1l, bl, gl, h0, hA);
+            if constexpr (HOIST) {
+                const float* sp = slot;
+                asm volatile("" : "+v"(sp));      // keep the slot reads inside the step loop (no LICM into 64 VGPRs)
+                layer_first_hoisted(sp, a10, hh == 0 ? y : 0.0f, gl, hA);
+            } else {
+                h0[0] = hh == 0 ? y : s0;
+                layer_first<K1>(w1l, bl, gl, h0, hA);
+            }
             layer_hidden(w2l, bl + kH, gl + kH, hA, hB);
             layer_hidden(w3l, bl + 2 * kH, gl + 2 * kH, hB, hA);
-
-            // lin4: eps = W4 . h3 + b4 (regression/model.py:51), two half-wave partial sums
             float part = 0.0f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -292,6 +358,7 @@ __global__ __launch_bounds__(kThreads, 2) void card_sample_guided_kernel(const R
                     for (int e = 0; e < 4; ++e) part = fmaf(hA[j][4 * q + e], w[e], part);
                 }
             }
+            // lin4: eps = W4 . h3 + b4 (regression/model.py:51), two half-wave partial sums
             const float eps = (part + __shfl_xor(part, 32, 64)) + b4;
 
             if (p.eps_only) {
@@ -343,6 +410,19 @@ __global__ void pack_first_kernel(const float* __restrict__ W1, int d_in, int K1
     const int e = idx & 3, l = (idx >> 2) & 63, rest = idx >> 8, q = rest % nq, j = rest / nq;
     const int n = 32 * j + (l & 31), k = 8 * q + 2 * e + (l >> 5);
     out[idx] = k < d_in ? W1[n * d_in + k] : 0.0f;
+}
+
+// HOIST kernels: static columns 1..d_in-1 of W1; k-step 4q+e of group q takes feature 1 + 8q + 2e + (l>>5)
+__global__ void pack_static_kernel(const float* __restrict__ W1, int d_in, int nqs, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= kH * 8 * nqs) return;
+    const int e = idx & 3, l = (idx >> 2) & 63, rest = idx >> 8, q = rest % nqs, j = rest / nqs;
+    const int n = 32 * j + (l & 31), k = 1 + 8 * q + 2 * e + (l >> 5);
+    out[idx] = k < d_in ? W1[n * d_in + k] : 0.0f;
+}
+
+__global__ void pack_col0_kernel(const float* __restrict__ W1, int d_in, float* __restrict__ out) {
+    out[threadIdx.x] = W1[threadIdx.x * d_in];  // 128 threads
 }
 
 __global__ void pack_misc_kernel(const float* b1, const float* b2, const float* b3, const float* W4,
@@ -427,12 +507,13 @@ int fail(int code, const char* fmt, ...) {
 
 typedef void (*sample_kernel_t)(const RunParams);
 
-sample_kernel_t guided_kernel_for(int k1) {
+sample_kernel_t guided_kernel_for(int k1, bool hoist) {
+    if (hoist) return card_sample_guided_kernel<8, true>;
     switch (k1) {
-        case 8: return card_sample_guided_kernel<8>;
-        case 16: return card_sample_guided_kernel<16>;
-        case 24: return card_sample_guided_kernel<24>;
-        case 32: return card_sample_guided_kernel<32>;
+        case 8: return card_sample_guided_kernel<8, false>;
+        case 16: return card_sample_guided_kernel<16, false>;
+        case 24: return card_sample_guided_kernel<24, false>;
+        case 32: return card_sample_guided_kernel<32, false>;
         default: return nullptr;
     }
 }
@@ -445,6 +526,9 @@ struct card_sampler {
     int device, num_cu;
     float* wpk;   // packed LDS image
     float* gtab;  // (n_embed, 3, 128)
+    int hoist, nqs;
+    float* w1s;   // hoist: packed static columns of W1
+    float* ws;    // hoist: per-wave scratch slots (num_cu * 8 * 16 KB)
     sample_kernel_t kernel;
     size_t lds_bytes;
 };
@@ -493,9 +577,14 @@ extern "C" CARD_API int card_sampler_create(const card_model_desc* d, void* stre
         if (!d->W[l] || !d->b[l] || !d->gamma[l]) return fail(CARD_E_INVALID, "card_sampler_create: null weight pointer (layer %d)", l + 1);
     if (!d->W4 || !d->b4) return fail(CARD_E_INVALID, "card_sampler_create: null lin4 pointer");
     const int d_in = d->y_dim + (d->cat_y_pred ? d->y_dim : 0) + (d->cat_x ? d->x_dim : 0);
-    const int k1 = (d_in + 7) / 8 * 8;
-    sample_kernel_t kern = guided_kernel_for(k1);
-    if (!kern) return fail(CARD_E_UNSUPPORTED, "card_sampler_create: d_in=%d (padded %d) exceeds the LDS-resident layer-1 limit of 32", d_in, k1);
+    // Layer 1: LDS-resident MFMA (d_in <= 32) or hoisted (any d_in).  CARD_AMD_HOIST=0/1 overrides the choice
+    // for A/B runs; d_in > 32 always hoists.
+    bool hoist = d_in > 32;
+    if (const char* ev = getenv("CARD_AMD_HOIST")) hoist = hoist || ev[0] == '1';
+    const int k1 = hoist ? 1 : (d_in + 7) / 8 * 8;
+    const int nqs = (d_in - 1 + 7) / 8;
+    sample_kernel_t kern = guided_kernel_for(k1, hoist);
+    if (!kern) return fail(CARD_E_UNSUPPORTED, "card_sampler_create: no kernel for d_in=%d", d_in);
 
     hipStream_t stream = (hipStream_t)stream_;
     card_sampler* s = new (std::nothrow) card_sampler();
@@ -503,6 +592,7 @@ extern "C" CARD_API int card_sampler_create(const card_model_desc* d, void* stre
     s->variant = d->variant; s->x_dim = d->x_dim; s->y_dim = d->y_dim; s->hidden = d->hidden;
     s->n_embed = d->n_embed; s->cat_x = d->cat_x ? 1 : 0; s->cat_y_pred = d->cat_y_pred ? 1 : 0;
     s->d_in = d_in; s->k1 = k1; s->kernel = kern; s->wpk = nullptr; s->gtab = nullptr;
+    s->hoist = hoist ? 1 : 0; s->nqs = nqs; s->w1s = nullptr; s->ws = nullptr;
     const int img = img_floats(k1);
     s->lds_bytes = (size_t)(img + kWaves * kGammaRow) * sizeof(float);
     hipError_t e;
@@ -510,13 +600,20 @@ extern "C" CARD_API int card_sampler_create(const card_model_desc* d, void* stre
         (e = hipDeviceGetAttribute(&s->num_cu, hipDeviceAttributeMultiprocessorCount, s->device)) != hipSuccess ||
         (e = hipMalloc(&s->wpk, (size_t)img * sizeof(float))) != hipSuccess ||
         (e = hipMalloc(&s->gtab, (size_t)d->n_embed * kGammaRow * sizeof(float))) != hipSuccess ||
+        (hoist && nqs > 0 && (e = hipMalloc(&s->w1s, (size_t)kH * 8 * nqs * sizeof(float))) != hipSuccess) ||
+        (hoist && (e = hipMalloc(&s->ws, (size_t)s->num_cu * kWaves * kSlotFloats * sizeof(float))) != hipSuccess) ||
         (e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes)) != hipSuccess) {
         card_sampler_destroy(s);
         return fail(CARD_E_HIP, "card_sampler_create: %s", hipGetErrorString(e));
     }
     pack_hidden_kernel<<<kH * kH / 256, 256, 0, stream>>>(d->W[1], kLn2, s->wpk + kOffW2);
     pack_hidden_kernel<<<kH * kH / 256, 256, 0, stream>>>(d->W[2], kLn2, s->wpk + kOffW3);
-    pack_first_kernel<<<(kH * k1 + 255) / 256, 256, 0, stream>>>(d->W[0], d_in, k1, s->wpk + kOffW1);
+    if (hoist) {
+        pack_col0_kernel<<<1, kH, 0, stream>>>(d->W[0], d_in, s->wpk + kOffW1);
+        if (nqs > 0) pack_static_kernel<<<(kH * 8 * nqs + 255) / 256, 256, 0, stream>>>(d->W[0], d_in, nqs, s->w1s);
+    } else {
+        pack_first_kernel<<<(kH * k1 + 255) / 256, 256, 0, stream>>>(d->W[0], d_in, k1, s->wpk + kOffW1);
+    }
     pack_misc_kernel<<<1, kH, 0, stream>>>(d->b[0], d->b[1], d->b[2], d->W4, d->b4, s->wpk);
     const int ng = d->n_embed * kGammaRow;
     pack_gamma_kernel<<<(ng + 255) / 256, 256, 0, stream>>>(d->gamma[0], d->gamma[1], d->gamma[2], d->n_embed, s->gtab);
@@ -532,6 +629,8 @@ extern "C" CARD_API void card_sampler_destroy(card_sampler* s) {
     if (!s) return;
     if (s->wpk) (void)hipFree(s->wpk);
     if (s->gtab) (void)hipFree(s->gtab);
+    if (s->w1s) (void)hipFree(s->w1s);
+    if (s->ws) (void)hipFree(s->ws);
     delete s;
 }
 
@@ -540,6 +639,7 @@ namespace {
 int launch_sampler(const card_sampler* s, RunParams p, hipStream_t stream) {
     // Split very large N into launches of whole waves-worth of tiles so that one launch stays well under
     // a second and every wave gets the same number of tiles (no intra-launch tail except in the last one).
+    p.w1s = s->w1s; p.ws = s->ws; p.nqs = s->nqs;
     const long long waves = (long long)s->num_cu * kWaves;
     const long long tiles_per_wave = 16;
     const long long chunk = waves * tiles_per_wave * kTileM;

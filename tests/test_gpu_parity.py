@@ -20,7 +20,7 @@ TOL = 1e-4
 DEV = "cuda:0"
 
 REG = [n for n in golden_names("reg")]
-SUPPORTED_REG = [n for n in REG if "year" not in n]
+SUPPORTED_REG = REG
 
 
 class RefShapedGuided(torch.nn.Module):
@@ -127,10 +127,32 @@ def test_q_sample_bit_exact(name):
     assert torch.equal(out, torch.from_numpy(d["q.out"]))
 
 
+def test_hoisted_layer1_equals_lds_resident_layer1(monkeypatch):
+    """CARD_AMD_HOIST=1 forces the any-d_in kernel (layer-1 static part hoisted to a per-wave scratch slot) on a
+    model the LDS-resident kernel also covers: both must meet the parity bar and agree closely with each other."""
+    for name in ("reg_boston_T50", "reg_toy_T50", "reg_yonly_T50", "reg_nocaty_T50"):
+        g = load_golden(name)
+        kw = dict(cat_x=g["cat_x"], cat_y_pred=g["cat_y_pred"], device=DEV)
+        monkeypatch.setenv("CARD_AMD_HOIST", "0")
+        a = Sampler.from_state_dict(g["sd"], **kw)
+        monkeypatch.setenv("CARD_AMD_HOIST", "1")
+        b = Sampler.from_state_dict(g["sd"], **kw)
+        ra = _raw_run(a, g, noise=cuda(g["noise"]), out_mode=_lib.OUT_ALL).cpu()
+        rb = _raw_run(b, g, noise=cuda(g["noise"]), out_mode=_lib.OUT_ALL).cpu()
+        ref = g["traj"]
+        assert max(norm_rel_err(rb[k], ref[i]) for i, k in enumerate(g["traj_idx"])) <= TOL
+        assert norm_rel_err(rb, ra) <= 1e-5
+        # many tiles per wave: slot reuse across tiles
+        reps = 700
+        big = _raw_run(b, g, N_rep=reps, noise=cuda(g["noise"].repeat(1, reps, 1))).cpu().reshape(reps, -1, 1)
+        assert torch.equal(big, big[:1].expand_as(big)) and torch.equal(big[0], rb[-1])
+
+
 def _raw_run(s, g, N_rep=1, **kw):
     rep = lambda t: cuda(t.repeat(N_rep, 1))
     coef = cuda(make_coef_table(g["alphas"], g["omabs"]))
-    return s.run(rep(g["x"]), rep(g["y0hat"]), rep(g["yTmean"]), coef, g["T"], **kw)
+    x = rep(g["x"]) if g["x"].shape[1] else None
+    return s.run(x, rep(g["y0hat"]), rep(g["yTmean"]), coef, g["T"], **kw)
 
 
 def test_rng_mode_equals_injected_mode_fed_with_its_own_draws():
