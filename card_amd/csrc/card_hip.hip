@@ -577,10 +577,10 @@ extern "C" CARD_API int card_sampler_create(const card_model_desc* d, void* stre
         if (!d->W[l] || !d->b[l] || !d->gamma[l]) return fail(CARD_E_INVALID, "card_sampler_create: null weight pointer (layer %d)", l + 1);
     if (!d->W4 || !d->b4) return fail(CARD_E_INVALID, "card_sampler_create: null lin4 pointer");
     const int d_in = d->y_dim + (d->cat_y_pred ? d->y_dim : 0) + (d->cat_x ? d->x_dim : 0);
-    // Layer 1: LDS-resident MFMA (d_in <= 32) or hoisted (any d_in).  CARD_AMD_HOIST=0/1 overrides the choice
-    // for A/B runs; d_in > 32 always hoists.
-    bool hoist = d_in > 32;
-    if (const char* ev = getenv("CARD_AMD_HOIST")) hoist = hoist || ev[0] == '1';
+    // Layer 1: hoisted (any d_in; default, 1.5-3.5 % faster at d_in 3-15 and the only form for d_in > 32) or
+    // LDS-resident MFMA every step (d_in <= 32, no scratch slots; CARD_AMD_HOIST=0 selects it for A/B runs).
+    bool hoist = true;
+    if (const char* ev = getenv("CARD_AMD_HOIST")) hoist = d_in > 32 || ev[0] != '0';
     const int k1 = hoist ? 1 : (d_in + 7) / 8 * 8;
     const int nqs = (d_in - 1 + 7) / 8;
     sample_kernel_t kern = guided_kernel_for(k1, hoist);

@@ -12,7 +12,9 @@
  *   - every call is stream-ordered on `stream` (a hipStream_t passed as void*; NULL = default stream) and
  *     never synchronises the device
  *   - return value: 0 = ok, negative = card_status; card_last_error() gives a thread-local message
- *   - a created sampler is immutable: concurrent card_sampler_run calls on different streams are safe
+ *   - a created sampler's weights are immutable; it also owns 16 KB of scratch per resident wave (32 MB) that
+ *     every launch reuses, so calls on ONE sampler must not overlap in time (same stream, or caller-ordered
+ *     streams).  Use one sampler per concurrent stream.
  *   - timestep index t runs T-1 ... 0 exactly like the reference's `reversed(range(1, n_steps))` + t = 0;
  *     "state index" s = T - t (s = 0 is y_T, s = T is y_0), i.e. position in the reference's y_p_seq list
  */
