@@ -80,6 +80,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
+    # stdout carries exactly one JSON line: route everything libraries print there (the RCCL banner ...) to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -88,7 +93,8 @@ def main():
             sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = "RANK" in os.environ          # launched by torch.distributed.run (also with one rank)
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
@@ -117,7 +123,7 @@ def main():
 
     def one_step(i):
         y = sampler.run(x, y0, y0, coef, T, seed=1234 + i, elem_offset=elem_offset, out_mode=_lib.OUT_LAST)
-        if world > 1:
+        if use_dist:
             # evaluation sums (n, squared error, PICP count, QICE bin counts: card_regression.py:776-821) of this
             # rank's rows, then ONE 15-element RCCL all-reduce per loop -- the only collective on the path
             sums = regression_metric_sums(y.reshape(a.rows, a.nz, 1), y_true)
@@ -125,7 +131,7 @@ def main():
         return y
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -144,7 +150,7 @@ def main():
     ev1.record()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -189,8 +195,9 @@ def main():
             out["cpu_baseline"] = {"value": v, "unit": "sample-steps/s", "cores": threads, "kind": "port",
                                    "sample": f"{steps_cpu} of the {T} timesteps of one reference minibatch "
                                              f"(256 rows x 1000 z = {rows_cpu} chains), torch CPU fp32, {dt:.1f} s"}
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if use_dist:
         dist.destroy_process_group()
 
 
