@@ -12,7 +12,7 @@ COEF_COLS = 8
 
 EXPORTS = (
     "card_version", "card_last_error", "card_make_coef_table", "card_sampler_create", "card_sampler_destroy",
-    "card_sampler_run", "card_eps_theta", "card_q_sample", "card_philox_normal",
+    "card_sampler_run", "card_sampler_workspace_bytes", "card_eps_theta", "card_q_sample", "card_philox_normal",
 )
 
 _fp = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
@@ -32,7 +32,7 @@ class RunArgs(C.Structure):
         ("struct_bytes", C.c_int32), ("T", C.c_int32), ("t_hi", C.c_int32), ("t_lo", C.c_int32),
         ("N", C.c_int64), ("x", _fp), ("y_0_hat", _fp), ("y_T_mean", _fp), ("y_init", _fp), ("coef", _fp),
         ("noise", _fp), ("seed", C.c_uint64), ("elem_offset", C.c_uint64), ("out", _fp),
-        ("out_mode", C.c_int32), ("state_slot", _fp),
+        ("out_mode", C.c_int32), ("state_slot", _fp), ("workspace", _fp), ("workspace_bytes", C.c_uint64),
     ]
 
 
@@ -60,7 +60,8 @@ def lib():
     L.card_sampler_destroy.argtypes = [C.c_void_p]
     L.card_sampler_destroy.restype = None
     L.card_sampler_run.argtypes = [C.c_void_p, C.POINTER(RunArgs), C.c_void_p]
-    L.card_eps_theta.argtypes = [C.c_void_p, _fp, _fp, _fp, C.c_int64, C.c_int32, _fp, C.c_void_p]
+    L.card_sampler_workspace_bytes.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_uint64)]
+    L.card_eps_theta.argtypes = [C.c_void_p, _fp, _fp, _fp, C.c_int64, C.c_int32, _fp, _fp, C.c_uint64, C.c_void_p]
     L.card_q_sample.argtypes = [_fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_uint64,
                                 C.c_uint64, _fp, C.c_void_p]
     L.card_philox_normal.argtypes = [C.c_uint64, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_void_p]

@@ -1,0 +1,210 @@
+// card_api.hip - the C ABI of libcard_hip.so (include/card_hip.h): argument checking, dispatch to the two
+// back ends (card_guided.hip: persistent MLP kernel; card_wide.hip: streaming-GEMM classification head),
+// plus the small stand-alone entry points (coefficient table, q_sample, RNG fill).
+#include <new>
+
+#include "card_internal.h"
+
+using namespace card;
+
+namespace {
+thread_local char g_err[512] = "";
+__global__ void q_sample_kernel(const float* __restrict__ y, const float* __restrict__ y0hat,
+                                const float* __restrict__ sab, const float* __restrict__ somab,
+                                const int64_t* __restrict__ t, long long n_elems, int y_dim,
+                                const float* __restrict__ noise, unsigned long long seed,
+                                unsigned long long elem_offset, float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_elems;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int64_t ti = t[i / y_dim];
+        const float a = sab[ti], s = somab[ti];
+        float e;
+        if (noise) {
+            e = noise[i];
+        } else {
+            float z[4];
+            philox_normal4(seed, elem_offset + (unsigned long long)i, 0u, z);
+            e = z[0];
+        }
+        // regression/diffusion_utils.py:52, left to right, no contraction
+        out[i] = (a * y[i] + (1.0f - a) * y0hat[i]) + s * e;
+    }
+}
+
+__global__ void philox_fill_kernel(unsigned long long seed, unsigned long long elem_offset, long long n_elems,
+                                   int draw0, int n_draws, float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_elems;
+         i += (long long)gridDim.x * blockDim.x) {
+        float z[4];
+        uint32_t blk = 0xFFFFFFFFu;
+        for (int k = 0; k < n_draws; ++k) {
+            const int d = draw0 + k;
+            if (((uint32_t)d >> 2) != blk) {
+                blk = (uint32_t)d >> 2;
+                philox_normal4(seed, elem_offset + (unsigned long long)i, blk, z);
+            }
+            out[(long long)k * n_elems + i] = pick4(z, d & 3);
+        }
+    }
+}
+
+}  // namespace
+
+int card_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define fail card_fail
+
+extern "C" CARD_API int card_version(void) { return CARD_HIP_VERSION; }
+extern "C" CARD_API const char* card_last_error(void) { return g_err; }
+
+extern "C" CARD_API int card_make_coef_table(const float* alphas, const float* omabs, int32_t T, float* out) {
+    if (!alphas || !omabs || !out || T < 1) return fail(CARD_E_INVALID, "card_make_coef_table: bad argument");
+    // regression/diffusion_utils.py:71-80, :88 in the same fp32 operation order (file built with
+    // -ffp-contract=off; sqrtf and / are correctly rounded, as torch's CPU kernels are)
+    for (int t = 0; t < T; ++t) {
+        float* r = out + (size_t)t * CARD_COEF_COLS;
+        const float s = omabs[t];
+        const float sab = sqrtf(1.0f - s * s);
+        r[CARD_COEF_INV_SQRT_AB] = 1.0f / sab;
+        r[CARD_COEF_ONE_M_SQRT_AB] = 1.0f - sab;
+        r[CARD_COEF_SOMAB] = s;
+        r[CARD_COEF_SQRT_AB] = sab;
+        r[CARD_COEF_G0] = r[CARD_COEF_G1] = r[CARD_COEF_G2] = r[CARD_COEF_SIGMA] = 0.0f;
+        if (t >= 1) {
+            const float a = alphas[t];
+            const float sm = omabs[t - 1];
+            const float sabm = sqrtf(1.0f - sm * sm);
+            const float s2 = s * s;
+            r[CARD_COEF_G0] = (1.0f - a) * sabm / s2;
+            r[CARD_COEF_G1] = (sm * sm) * sqrtf(a) / s2;
+            r[CARD_COEF_G2] = 1.0f + (sab - 1.0f) * (sqrtf(a) + sabm) / s2;
+            r[CARD_COEF_SIGMA] = sqrtf((sm * sm) / s2 * (1.0f - a));
+        }
+    }
+    return CARD_OK;
+}
+
+extern "C" CARD_API int card_sampler_create(const card_model_desc* d, void* stream_, card_sampler** out) {
+    if (!d || !out) return fail(CARD_E_INVALID, "card_sampler_create: null argument");
+    *out = nullptr;
+    if (d->struct_bytes != (int32_t)sizeof(card_model_desc))
+        return fail(CARD_E_INVALID, "card_sampler_create: struct_bytes %d != %zu", d->struct_bytes, sizeof(card_model_desc));
+    if (d->variant != CARD_VARIANT_GUIDED && d->variant != CARD_VARIANT_BN_HADAMARD)
+        return fail(CARD_E_INVALID, "card_sampler_create: unknown variant %d", d->variant);
+    if (d->n_embed < 1 || d->x_dim < 0 || d->y_dim < 1 || d->hidden < 1) return fail(CARD_E_INVALID, "card_sampler_create: bad n_embed/x_dim/y_dim/hidden");
+    for (int l = 0; l < 3; ++l)
+        if (!d->W[l] || !d->b[l] || !d->gamma[l]) return fail(CARD_E_INVALID, "card_sampler_create: null weight pointer (layer %d)", l + 1);
+    if (!d->W4 || !d->b4) return fail(CARD_E_INVALID, "card_sampler_create: null lin4 pointer");
+    card_sampler* s = new (std::nothrow) card_sampler();
+    if (!s) return fail(CARD_E_NOMEM, "card_sampler_create: out of host memory");
+    memset(s, 0, sizeof(*s));
+    s->variant = d->variant; s->x_dim = d->x_dim; s->y_dim = d->y_dim; s->hidden = d->hidden;
+    s->n_embed = d->n_embed; s->cat_x = d->cat_x ? 1 : 0; s->cat_y_pred = d->cat_y_pred ? 1 : 0;
+    s->d_in = d->variant == CARD_VARIANT_GUIDED
+                  ? d->y_dim + (d->cat_y_pred ? d->y_dim : 0) + (d->cat_x ? d->x_dim : 0)
+                  : d->y_dim * (d->cat_y_pred ? 2 : 1);
+    hipError_t e;
+    if ((e = hipGetDevice(&s->device)) != hipSuccess ||
+        (e = hipDeviceGetAttribute(&s->num_cu, hipDeviceAttributeMultiprocessorCount, s->device)) != hipSuccess) {
+        delete s;
+        return fail(CARD_E_HIP, "card_sampler_create: %s", hipGetErrorString(e));
+    }
+    const int rc = d->variant == CARD_VARIANT_GUIDED ? guided_create(s, d, (hipStream_t)stream_)
+                                                     : wide_create(s, d, (hipStream_t)stream_);
+    if (rc != CARD_OK) {
+        card_sampler_destroy(s);
+        return rc;
+    }
+    *out = s;
+    return CARD_OK;
+}
+
+extern "C" CARD_API void card_sampler_destroy(card_sampler* s) {
+    if (!s) return;
+    if (s->variant == CARD_VARIANT_GUIDED) guided_destroy(s);
+    else wide_destroy(s);
+    delete s;
+}
+
+extern "C" CARD_API int card_sampler_workspace_bytes(const card_sampler* s, int64_t N, uint64_t* bytes) {
+    if (!s || !bytes || N < 0) return fail(CARD_E_INVALID, "card_sampler_workspace_bytes: bad argument");
+    *bytes = s->variant == CARD_VARIANT_BN_HADAMARD ? wide_workspace_bytes(s, N) : 0;
+    return CARD_OK;
+}
+
+extern "C" CARD_API int card_sampler_run(const card_sampler* s, const card_run_args* a, void* stream) {
+    if (!s || !a) return fail(CARD_E_INVALID, "card_sampler_run: null argument");
+    if (a->struct_bytes != (int32_t)sizeof(card_run_args))
+        return fail(CARD_E_INVALID, "card_sampler_run: struct_bytes %d != %zu", a->struct_bytes, sizeof(card_run_args));
+    if (a->N < 0) return fail(CARD_E_INVALID, "card_sampler_run: N < 0");
+    if (a->T < 1 || a->T > s->n_embed)
+        return fail(CARD_E_INVALID, "card_sampler_run: T=%d outside [1, n_embed=%d]", a->T, s->n_embed);
+    if (a->t_lo < 0 || a->t_hi < a->t_lo || a->t_hi >= a->T)
+        return fail(CARD_E_INVALID, "card_sampler_run: need 0 <= t_lo <= t_hi < T (got %d, %d, T=%d)", a->t_lo, a->t_hi, a->T);
+    if (!a->y_init && a->t_hi != a->T - 1)
+        return fail(CARD_E_INVALID, "card_sampler_run: y_init == NULL starts a loop and needs t_hi == T-1");
+    if (a->out_mode < CARD_OUT_LAST || a->out_mode > CARD_OUT_SELECT) return fail(CARD_E_INVALID, "card_sampler_run: bad out_mode");
+    if (a->N == 0) return CARD_OK;  // empty batch: nothing to read or write
+    if (!a->y_0_hat || !a->y_T_mean || !a->coef || !a->out)
+        return fail(CARD_E_INVALID, "card_sampler_run: null y_0_hat / y_T_mean / coef / out");
+    const bool need_x = s->variant == CARD_VARIANT_BN_HADAMARD || (s->cat_x && s->x_dim > 0);
+    if (need_x && !a->x) return fail(CARD_E_INVALID, "card_sampler_run: x is NULL but the model reads x");
+    if (a->out_mode == CARD_OUT_SELECT && !a->state_slot) return fail(CARD_E_INVALID, "card_sampler_run: CARD_OUT_SELECT needs state_slot");
+    CardRun r;
+    memset(&r, 0, sizeof(r));
+    r.x = a->x; r.y0hat = a->y_0_hat; r.ytmean = a->y_T_mean; r.y_init = a->y_init; r.coef = a->coef;
+    r.noise = a->noise; r.out = a->out; r.state_slot = a->state_slot;
+    r.workspace = a->workspace; r.workspace_bytes = a->workspace_bytes;
+    r.N = a->N; r.seed = a->seed; r.elem_offset = a->elem_offset;
+    r.T = a->T; r.t_hi = a->t_hi; r.t_lo = a->t_lo; r.out_mode = a->out_mode; r.eps_only = 0;
+    return s->variant == CARD_VARIANT_GUIDED ? guided_run(s, r, (hipStream_t)stream) : wide_run(s, r, (hipStream_t)stream);
+}
+
+extern "C" CARD_API int card_eps_theta(const card_sampler* s, const float* x, const float* y_t, const float* y_0_hat,
+                                       int64_t N, int32_t t, float* out, void* workspace, uint64_t workspace_bytes,
+                                       void* stream) {
+    if (!s || !y_t || !y_0_hat || !out) return fail(CARD_E_INVALID, "card_eps_theta: null argument");
+    const bool need_x = s->variant == CARD_VARIANT_BN_HADAMARD || (s->cat_x && s->x_dim > 0);
+    if (need_x && !x) return fail(CARD_E_INVALID, "card_eps_theta: x is NULL but the model reads x");
+    if (t < 0 || t >= s->n_embed) return fail(CARD_E_INVALID, "card_eps_theta: t=%d outside the gamma table", t);
+    if (N < 0) return fail(CARD_E_INVALID, "card_eps_theta: N < 0");
+    if (N == 0) return CARD_OK;
+    CardRun r;
+    memset(&r, 0, sizeof(r));
+    r.x = x; r.y0hat = y_0_hat; r.ytmean = y_0_hat; r.y_init = y_t; r.out = out; r.N = N;
+    r.workspace = workspace; r.workspace_bytes = workspace_bytes;
+    r.T = t + 1; r.t_hi = t; r.t_lo = t; r.out_mode = CARD_OUT_LAST; r.eps_only = 1;
+    return s->variant == CARD_VARIANT_GUIDED ? guided_run(s, r, (hipStream_t)stream) : wide_run(s, r, (hipStream_t)stream);
+}
+
+extern "C" CARD_API int card_q_sample(const float* y, const float* y_0_hat, const float* sab, const float* somab,
+                             const int64_t* t, int64_t N, int32_t y_dim, int32_t T, const float* noise, uint64_t seed,
+                             uint64_t elem_offset, float* out, void* stream) {
+    (void)T;
+    if (!y || !y_0_hat || !sab || !somab || !t || !out) return fail(CARD_E_INVALID, "card_q_sample: null argument");
+    if (N < 0 || y_dim < 1) return fail(CARD_E_INVALID, "card_q_sample: bad N / y_dim");
+    if (N == 0) return CARD_OK;
+    const long long n = (long long)N * y_dim;
+    long long grid = (n + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    q_sample_kernel<<<dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream>>>(y, y_0_hat, sab, somab, t, n, y_dim, noise, seed,
+                                                                                  elem_offset, out);
+    HIP_TRY(hipGetLastError());
+    return CARD_OK;
+}
+
+extern "C" CARD_API int card_philox_normal(uint64_t seed, uint64_t elem_offset, int64_t n_elems, int32_t draw0, int32_t n_draws,
+                                  float* out, void* stream) {
+    if (!out || n_elems < 0 || draw0 < 0 || n_draws < 0) return fail(CARD_E_INVALID, "card_philox_normal: bad argument");
+    if (n_elems == 0 || n_draws == 0) return CARD_OK;
+    long long grid = (n_elems + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    philox_fill_kernel<<<dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream>>>(seed, elem_offset, n_elems, draw0, n_draws, out);
+    HIP_TRY(hipGetLastError());
+    return CARD_OK;
+}

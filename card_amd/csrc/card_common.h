@@ -1,0 +1,79 @@
+// card_common.h - shared device helpers of libcard_hip.so (gfx950).
+#ifndef CARD_COMMON_H
+#define CARD_COMMON_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <math.h>
+
+#include "card_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace card {
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr float kSpThresh = 20.0f * 1.4426950408889634f;  // softplus threshold 20 in log2 units
+
+// ------------------------------------------------------------------------------------------------
+// RNG: Philox4x32-10 (Salmon et al. 2011) + Box-Muller.  Restated in oracle/card_oracle.py:philox_normal.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&o)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+__device__ __forceinline__ float u01(uint32_t r) { return ((float)(r >> 9) + 0.5f) * 1.1920928955078125e-07f; }
+
+// four standard normals for (element, draw block)
+__device__ __forceinline__ void philox_normal4(unsigned long long seed, unsigned long long elem, uint32_t block,
+                                               float (&z)[4]) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)elem, (uint32_t)(elem >> 32), block, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const float rad = sqrtf(-2.0f * logf(u01(r[2 * p])));
+        float s, c;
+        sincospif(2.0f * u01(r[2 * p + 1]), &s, &c);
+        z[2 * p] = rad * c;
+        z[2 * p + 1] = rad * s;
+    }
+}
+
+__device__ __forceinline__ float pick4(const float (&z)[4], int i) {
+    return i == 0 ? z[0] : (i == 1 ? z[1] : (i == 2 ? z[2] : z[3]));
+}
+
+// softplus(x)/ln2 with x given in log2 units: F.softplus(beta=1, threshold=20) (regression/model.py:48-50)
+__device__ __forceinline__ float softplus_l2(float xs) {
+    const float e = __builtin_amdgcn_exp2f(xs);
+    const float l = __builtin_amdgcn_logf(1.0f + e);
+    return xs > kSpThresh ? xs : l;
+}
+
+__device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+
+}  // namespace card
+
+// host-side error plumbing (defined in card_api.hip)
+int card_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) return card_fail(CARD_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+#endif

@@ -1,33 +1,26 @@
-// libcard_hip.so - CARD reverse-diffusion sampler for MI355X (gfx950 / CDNA4).
+// card_guided.hip - the persistent sampler kernel for CARD_VARIANT_GUIDED (regression ConditionalGuidedModel).
 //
-// One persistent kernel runs all T timesteps of p_sample_loop (reference:
-// regression/diffusion_utils.py:107-119) for N independent (row, z) chains:
-//   * a wave owns a tile of 32 chains for the whole loop; y_t, y_0_hat, y_T_mean and the x part of the
-//     layer-1 input stay in registers for all T steps
+// One launch runs all T timesteps of p_sample_loop (reference: regression/diffusion_utils.py:107-119) for up
+// to 1 048 576 independent (row, z) chains:
+//   * a wave owns a tile of 32 chains for the whole loop; y_t, y_T_mean and the layer-1 state stay on chip
 //   * activations are kept TRANSPOSED (feature x chain): a 32x32 fp32 MFMA accumulator of layer l is,
 //     register for register, the B operand of layer l+1 (v_mfma_f32_32x32x2_f32 sums over the
-//     accumulator's row index), so the whole MLP chains through registers with no cross-lane traffic
-//   * W1..W3, biases and W4 live in LDS for the whole kernel in "fragment order" (one ds_read_b128 per
+//     accumulator's row index), so the MLP chains through registers with no cross-lane traffic
+//   * W2, W3, biases and W4 live in LDS for the whole kernel in "fragment order" (one ds_read_b128 per
 //     lane yields the A operands of four consecutive MFMAs, conflict-free); per-step gamma rows are staged
 //     through a small wave-private LDS slab, prefetched one step ahead
+//   * layer 1: the step-invariant part b1 + W1[:,1:].(y_0_hat, x) is computed once per tile into a per-wave
+//     16 KB scratch slot (re-read from L2 each step) and one K=2 MFMA per output tile adds W1[:,0]*y_t
+//     (HOIST, any d_in); or, without scratch, W1 stays in LDS and layer 1 runs on MFMA every step (d_in <= 32)
 //   * epilogue per element: xs = acc * (gamma*log2e); softplus/ln2 = xs > 20*log2e ? xs : log2(1 + exp2(xs))
 //     (ln2 is folded into the next layer's weights), i.e. F.softplus(beta=1, threshold=20)
+//   * measured on gfx950: v_mfma_f32_32x32x2_f32 does NOT overlap with VALU work of either wave of a SIMD
+//     (tools/ubench), so MFMA and epilogue are issued as large blocks and the kernel's ceiling is
+//     MFMA time / (MFMA time + VALU time)
 //   * noise: injected (validation) or Philox4x32-10 + Box-Muller keyed by (seed, element, draw)
-//
-// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (explicit fmaf where fusion is wanted).
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdio.h>
-#include <string.h>
-#include <stdarg.h>
-#include <math.h>
-#include <stdlib.h>
-#include <new>
+#include "card_internal.h"
 
-#include "card_hip.h"
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+using namespace card;
 
 namespace {
 
@@ -35,9 +28,6 @@ constexpr int kH = 128;            // hidden width (regression/model.py:32-35)
 constexpr int kWaves = 8;          // waves per workgroup: 2 per SIMD, one workgroup per CU
 constexpr int kThreads = kWaves * 64;
 constexpr int kTileM = 32;         // chains per wave tile (the MFMA's 32 columns)
-constexpr float kLog2e = 1.4426950408889634f;
-constexpr float kLn2 = 0.6931471805599453f;
-constexpr float kSpThresh = 20.0f * 1.4426950408889634f;  // softplus threshold 20 in log2 units
 
 // LDS image (floats), copied verbatim from the packed device buffer at kernel start.
 constexpr int kOffW2 = 0;                 // 128x128 in fragment order
@@ -50,7 +40,9 @@ constexpr int kSlotFloats = kTileM * kH;  // one wave's hoisted layer-1 tile (32
 __host__ __device__ constexpr int img_floats(int k1) { return kOffW1 + kH * k1; }
 constexpr int kGammaRow = 3 * kH;         // one timestep's gamma*log2e for the 3 layers
 
-struct RunParams {
+}  // namespace
+
+struct GuidedParams {
     const float* wpk;     // packed LDS image
     const float* gtab;    // (n_embed, 3, 128) gamma * log2e
     const float* coef;    // (T, 8)
@@ -76,51 +68,9 @@ struct RunParams {
     int nqs;              // ceil((d_in - 1) / 8)
 };
 
-// ------------------------------------------------------------------------------------------------
-// RNG: Philox4x32-10 (Salmon et al. 2011) + Box-Muller.  Restated in oracle/card_oracle.py:philox_normal.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                              uint32_t k1, uint32_t (&o)[4]) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
-}
 
-__device__ __forceinline__ float u01(uint32_t r) { return ((float)(r >> 9) + 0.5f) * 1.1920928955078125e-07f; }
-
-// four standard normals for (element, draw block)
-__device__ __forceinline__ void philox_normal4(unsigned long long seed, unsigned long long elem, uint32_t block,
-                                               float (&z)[4]) {
-    uint32_t r[4];
-    philox4x32_10((uint32_t)elem, (uint32_t)(elem >> 32), block, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const float rad = sqrtf(-2.0f * logf(u01(r[2 * p])));
-        float s, c;
-        sincospif(2.0f * u01(r[2 * p + 1]), &s, &c);
-        z[2 * p] = rad * c;
-        z[2 * p + 1] = rad * s;
-    }
-}
-
-__device__ __forceinline__ float pick4(const float (&z)[4], int i) {
-    return i == 0 ? z[0] : (i == 1 ? z[1] : (i == 2 ? z[2] : z[3]));
-}
-
-// softplus(x)/ln2 with x given in log2 units: F.softplus(beta=1, threshold=20) (regression/model.py:48-50)
-__device__ __forceinline__ float softplus_l2(float xs) {
-    const float e = __builtin_amdgcn_exp2f(xs);
-    const float l = __builtin_amdgcn_logf(1.0f + e);
-    return xs > kSpThresh ? xs : l;
-}
-
-__device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+namespace {
+typedef GuidedParams RunParams;
 
 // gamma multiply + softplus of one 32-feature x 32-chain accumulator tile, in place
 __device__ __forceinline__ void epilogue_tile(f32x16& acc, const float* gl, int j) {
@@ -444,66 +394,6 @@ __global__ void pack_gamma_kernel(const float* g1, const float* g2, const float*
     gtab[idx] = g[t * kH + n] * kLog2e;
 }
 
-// ------------------------------------------------------------------------------------------------
-// q_sample and the RNG fill
-// ------------------------------------------------------------------------------------------------
-__global__ void q_sample_kernel(const float* __restrict__ y, const float* __restrict__ y0hat,
-                                const float* __restrict__ sab, const float* __restrict__ somab,
-                                const int64_t* __restrict__ t, long long n_elems, int y_dim,
-                                const float* __restrict__ noise, unsigned long long seed,
-                                unsigned long long elem_offset, float* __restrict__ out) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_elems;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int64_t ti = t[i / y_dim];
-        const float a = sab[ti], s = somab[ti];
-        float e;
-        if (noise) {
-            e = noise[i];
-        } else {
-            float z[4];
-            philox_normal4(seed, elem_offset + (unsigned long long)i, 0u, z);
-            e = z[0];
-        }
-        // regression/diffusion_utils.py:52, left to right, no contraction
-        out[i] = (a * y[i] + (1.0f - a) * y0hat[i]) + s * e;
-    }
-}
-
-__global__ void philox_fill_kernel(unsigned long long seed, unsigned long long elem_offset, long long n_elems,
-                                   int draw0, int n_draws, float* __restrict__ out) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_elems;
-         i += (long long)gridDim.x * blockDim.x) {
-        float z[4];
-        uint32_t blk = 0xFFFFFFFFu;
-        for (int k = 0; k < n_draws; ++k) {
-            const int d = draw0 + k;
-            if (((uint32_t)d >> 2) != blk) {
-                blk = (uint32_t)d >> 2;
-                philox_normal4(seed, elem_offset + (unsigned long long)i, blk, z);
-            }
-            out[(long long)k * n_elems + i] = pick4(z, d & 3);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// host side
-// ------------------------------------------------------------------------------------------------
-thread_local char g_err[512] = "";
-
-int fail(int code, const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-    return code;
-}
-
-#define HIP_TRY(expr)                                                                          \
-    do {                                                                                       \
-        hipError_t e_ = (expr);                                                                \
-        if (e_ != hipSuccess) return fail(CARD_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
 
 typedef void (*sample_kernel_t)(const RunParams);
 
@@ -520,63 +410,10 @@ sample_kernel_t guided_kernel_for(int k1, bool hoist) {
 
 }  // namespace
 
-struct card_sampler {
-    int variant, x_dim, y_dim, hidden, n_embed, cat_x, cat_y_pred;
-    int d_in, k1;
-    int device, num_cu;
-    float* wpk;   // packed LDS image
-    float* gtab;  // (n_embed, 3, 128)
-    int hoist, nqs;
-    float* w1s;   // hoist: packed static columns of W1
-    float* ws;    // hoist: per-wave scratch slots (num_cu * 8 * 16 KB)
-    sample_kernel_t kernel;
-    size_t lds_bytes;
-};
-
-extern "C" CARD_API int card_version(void) { return CARD_HIP_VERSION; }
-extern "C" CARD_API const char* card_last_error(void) { return g_err; }
-
-extern "C" CARD_API int card_make_coef_table(const float* alphas, const float* omabs, int32_t T, float* out) {
-    if (!alphas || !omabs || !out || T < 1) return fail(CARD_E_INVALID, "card_make_coef_table: bad argument");
-    // regression/diffusion_utils.py:71-80, :88 in the same fp32 operation order (file built with
-    // -ffp-contract=off; sqrtf and / are correctly rounded, as torch's CPU kernels are)
-    for (int t = 0; t < T; ++t) {
-        float* r = out + (size_t)t * CARD_COEF_COLS;
-        const float s = omabs[t];
-        const float sab = sqrtf(1.0f - s * s);
-        r[CARD_COEF_INV_SQRT_AB] = 1.0f / sab;
-        r[CARD_COEF_ONE_M_SQRT_AB] = 1.0f - sab;
-        r[CARD_COEF_SOMAB] = s;
-        r[CARD_COEF_SQRT_AB] = sab;
-        r[CARD_COEF_G0] = r[CARD_COEF_G1] = r[CARD_COEF_G2] = r[CARD_COEF_SIGMA] = 0.0f;
-        if (t >= 1) {
-            const float a = alphas[t];
-            const float sm = omabs[t - 1];
-            const float sabm = sqrtf(1.0f - sm * sm);
-            const float s2 = s * s;
-            r[CARD_COEF_G0] = (1.0f - a) * sabm / s2;
-            r[CARD_COEF_G1] = (sm * sm) * sqrtf(a) / s2;
-            r[CARD_COEF_G2] = 1.0f + (sab - 1.0f) * (sqrtf(a) + sabm) / s2;
-            r[CARD_COEF_SIGMA] = sqrtf((sm * sm) / s2 * (1.0f - a));
-        }
-    }
-    return CARD_OK;
-}
-
-extern "C" CARD_API int card_sampler_create(const card_model_desc* d, void* stream_, card_sampler** out) {
-    if (!d || !out) return fail(CARD_E_INVALID, "card_sampler_create: null argument");
-    *out = nullptr;
-    if (d->struct_bytes != (int32_t)sizeof(card_model_desc))
-        return fail(CARD_E_INVALID, "card_sampler_create: struct_bytes %d != %zu", d->struct_bytes, sizeof(card_model_desc));
-    if (d->variant != CARD_VARIANT_GUIDED)
-        return fail(CARD_E_UNSUPPORTED, "card_sampler_create: variant %d not built yet", d->variant);
-    if (d->hidden != kH) return fail(CARD_E_UNSUPPORTED, "card_sampler_create: hidden=%d, only 128 is built", d->hidden);
-    if (d->y_dim != 1) return fail(CARD_E_UNSUPPORTED, "card_sampler_create: y_dim=%d, only 1 is built", d->y_dim);
-    if (d->n_embed < 1 || d->x_dim < 0) return fail(CARD_E_INVALID, "card_sampler_create: bad n_embed/x_dim");
-    for (int l = 0; l < 3; ++l)
-        if (!d->W[l] || !d->b[l] || !d->gamma[l]) return fail(CARD_E_INVALID, "card_sampler_create: null weight pointer (layer %d)", l + 1);
-    if (!d->W4 || !d->b4) return fail(CARD_E_INVALID, "card_sampler_create: null lin4 pointer");
-    const int d_in = d->y_dim + (d->cat_y_pred ? d->y_dim : 0) + (d->cat_x ? d->x_dim : 0);
+int guided_create(card_sampler* s, const card_model_desc* d, hipStream_t stream) {
+    if (d->hidden != kH) return card_fail(CARD_E_UNSUPPORTED, "card_sampler_create: GUIDED hidden=%d, only 128 is built", d->hidden);
+    if (d->y_dim != 1) return card_fail(CARD_E_UNSUPPORTED, "card_sampler_create: GUIDED y_dim=%d, only 1 is built", d->y_dim);
+    const int d_in = s->d_in;
     // Layer 1: hoisted (any d_in; default, 1.5-3.5 % faster at d_in 3-15 and the only form for d_in > 32) or
     // LDS-resident MFMA every step (d_in <= 32, no scratch slots; CARD_AMD_HOIST=0 selects it for A/B runs).
     bool hoist = true;
@@ -584,28 +421,15 @@ extern "C" CARD_API int card_sampler_create(const card_model_desc* d, void* stre
     const int k1 = hoist ? 1 : (d_in + 7) / 8 * 8;
     const int nqs = (d_in - 1 + 7) / 8;
     sample_kernel_t kern = guided_kernel_for(k1, hoist);
-    if (!kern) return fail(CARD_E_UNSUPPORTED, "card_sampler_create: no kernel for d_in=%d", d_in);
-
-    hipStream_t stream = (hipStream_t)stream_;
-    card_sampler* s = new (std::nothrow) card_sampler();
-    if (!s) return fail(CARD_E_NOMEM, "card_sampler_create: out of host memory");
-    s->variant = d->variant; s->x_dim = d->x_dim; s->y_dim = d->y_dim; s->hidden = d->hidden;
-    s->n_embed = d->n_embed; s->cat_x = d->cat_x ? 1 : 0; s->cat_y_pred = d->cat_y_pred ? 1 : 0;
-    s->d_in = d_in; s->k1 = k1; s->kernel = kern; s->wpk = nullptr; s->gtab = nullptr;
-    s->hoist = hoist ? 1 : 0; s->nqs = nqs; s->w1s = nullptr; s->ws = nullptr;
+    if (!kern) return card_fail(CARD_E_UNSUPPORTED, "card_sampler_create: no kernel for d_in=%d", d_in);
+    s->k1 = k1; s->kernel = kern; s->hoist = hoist ? 1 : 0; s->nqs = nqs;
     const int img = img_floats(k1);
     s->lds_bytes = (size_t)(img + kWaves * kGammaRow) * sizeof(float);
-    hipError_t e;
-    if ((e = hipGetDevice(&s->device)) != hipSuccess ||
-        (e = hipDeviceGetAttribute(&s->num_cu, hipDeviceAttributeMultiprocessorCount, s->device)) != hipSuccess ||
-        (e = hipMalloc(&s->wpk, (size_t)img * sizeof(float))) != hipSuccess ||
-        (e = hipMalloc(&s->gtab, (size_t)d->n_embed * kGammaRow * sizeof(float))) != hipSuccess ||
-        (hoist && nqs > 0 && (e = hipMalloc(&s->w1s, (size_t)kH * 8 * nqs * sizeof(float))) != hipSuccess) ||
-        (hoist && (e = hipMalloc(&s->ws, (size_t)s->num_cu * kWaves * kSlotFloats * sizeof(float))) != hipSuccess) ||
-        (e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes)) != hipSuccess) {
-        card_sampler_destroy(s);
-        return fail(CARD_E_HIP, "card_sampler_create: %s", hipGetErrorString(e));
-    }
+    HIP_TRY(hipMalloc(&s->wpk, (size_t)img * sizeof(float)));
+    HIP_TRY(hipMalloc(&s->gtab, (size_t)d->n_embed * kGammaRow * sizeof(float)));
+    if (hoist && nqs > 0) HIP_TRY(hipMalloc(&s->w1s, (size_t)kH * 8 * nqs * sizeof(float)));
+    if (hoist) HIP_TRY(hipMalloc(&s->ws, (size_t)s->num_cu * kWaves * kSlotFloats * sizeof(float)));
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
     pack_hidden_kernel<<<kH * kH / 256, 256, 0, stream>>>(d->W[1], kLn2, s->wpk + kOffW2);
     pack_hidden_kernel<<<kH * kH / 256, 256, 0, stream>>>(d->W[2], kLn2, s->wpk + kOffW3);
     if (hoist) {
@@ -617,29 +441,29 @@ extern "C" CARD_API int card_sampler_create(const card_model_desc* d, void* stre
     pack_misc_kernel<<<1, kH, 0, stream>>>(d->b[0], d->b[1], d->b[2], d->W4, d->b4, s->wpk);
     const int ng = d->n_embed * kGammaRow;
     pack_gamma_kernel<<<(ng + 255) / 256, 256, 0, stream>>>(d->gamma[0], d->gamma[1], d->gamma[2], d->n_embed, s->gtab);
-    if ((e = hipGetLastError()) != hipSuccess) {
-        card_sampler_destroy(s);
-        return fail(CARD_E_HIP, "card_sampler_create: pack launch: %s", hipGetErrorString(e));
-    }
-    *out = s;
+    HIP_TRY(hipGetLastError());
     return CARD_OK;
 }
 
-extern "C" CARD_API void card_sampler_destroy(card_sampler* s) {
-    if (!s) return;
+void guided_destroy(card_sampler* s) {
     if (s->wpk) (void)hipFree(s->wpk);
     if (s->gtab) (void)hipFree(s->gtab);
     if (s->w1s) (void)hipFree(s->w1s);
     if (s->ws) (void)hipFree(s->ws);
-    delete s;
 }
 
-namespace {
-
-int launch_sampler(const card_sampler* s, RunParams p, hipStream_t stream) {
+int guided_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
+    RunParams p;
+    memset(&p, 0, sizeof(p));
+    p.wpk = s->wpk; p.gtab = s->gtab; p.coef = r.coef; p.x = r.x; p.y0hat = r.y0hat; p.ytmean = r.ytmean;
+    p.y_init = r.y_init; p.noise = r.noise; p.out = r.out; p.state_slot = r.state_slot;
+    p.N = r.N; p.seed = r.seed; p.elem_offset = r.elem_offset;
+    p.T = r.T; p.t_hi = r.t_hi; p.t_lo = r.t_lo;
+    p.x_dim = s->x_dim; p.cat_x = s->cat_x; p.cat_y_pred = s->cat_y_pred;
+    p.out_mode = r.out_mode; p.eps_only = r.eps_only;
+    p.w1s = s->w1s; p.ws = s->ws; p.nqs = s->nqs;
     // Split very large N into launches of whole waves-worth of tiles so that one launch stays well under
     // a second and every wave gets the same number of tiles (no intra-launch tail except in the last one).
-    p.w1s = s->w1s; p.ws = s->ws; p.nqs = s->nqs;
     const long long waves = (long long)s->num_cu * kWaves;
     const long long tiles_per_wave = 16;
     const long long chunk = waves * tiles_per_wave * kTileM;
@@ -650,82 +474,7 @@ int launch_sampler(const card_sampler* s, RunParams p, hipStream_t stream) {
         long long grid = (tiles + kWaves - 1) / kWaves;
         if (grid > s->num_cu) grid = s->num_cu;
         s->kernel<<<dim3((unsigned)grid), dim3(kThreads), s->lds_bytes, stream>>>(p);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return fail(CARD_E_HIP, "sampler launch: %s", hipGetErrorString(e));
+        HIP_TRY(hipGetLastError());
     }
-    return CARD_OK;
-}
-
-}  // namespace
-
-extern "C" CARD_API int card_sampler_run(const card_sampler* s, const card_run_args* a, void* stream) {
-    if (!s || !a) return fail(CARD_E_INVALID, "card_sampler_run: null argument");
-    if (a->struct_bytes != (int32_t)sizeof(card_run_args))
-        return fail(CARD_E_INVALID, "card_sampler_run: struct_bytes %d != %zu", a->struct_bytes, sizeof(card_run_args));
-    if (a->N < 0) return fail(CARD_E_INVALID, "card_sampler_run: N < 0");
-    if (a->T < 1 || a->T > s->n_embed)
-        return fail(CARD_E_INVALID, "card_sampler_run: T=%d outside [1, n_embed=%d]", a->T, s->n_embed);
-    if (a->t_lo < 0 || a->t_hi < a->t_lo || a->t_hi >= a->T)
-        return fail(CARD_E_INVALID, "card_sampler_run: need 0 <= t_lo <= t_hi < T (got %d, %d, T=%d)", a->t_lo, a->t_hi, a->T);
-    if (!a->y_init && a->t_hi != a->T - 1)
-        return fail(CARD_E_INVALID, "card_sampler_run: y_init == NULL starts a loop and needs t_hi == T-1");
-    if (a->N == 0) return CARD_OK;  // empty batch: nothing to read or write
-    if (!a->y_0_hat || !a->y_T_mean || !a->coef || !a->out)
-        return fail(CARD_E_INVALID, "card_sampler_run: null y_0_hat / y_T_mean / coef / out");
-    if (s->cat_x && s->x_dim > 0 && !a->x) return fail(CARD_E_INVALID, "card_sampler_run: x is NULL but the model concatenates x");
-    if (a->out_mode < CARD_OUT_LAST || a->out_mode > CARD_OUT_SELECT) return fail(CARD_E_INVALID, "card_sampler_run: bad out_mode");
-    if (a->out_mode == CARD_OUT_SELECT && !a->state_slot) return fail(CARD_E_INVALID, "card_sampler_run: CARD_OUT_SELECT needs state_slot");
-    RunParams p;
-    memset(&p, 0, sizeof(p));
-    p.wpk = s->wpk; p.gtab = s->gtab; p.coef = a->coef; p.x = a->x; p.y0hat = a->y_0_hat; p.ytmean = a->y_T_mean;
-    p.y_init = a->y_init; p.noise = a->noise; p.out = a->out; p.state_slot = a->state_slot;
-    p.N = a->N; p.seed = a->seed; p.elem_offset = a->elem_offset;
-    p.T = a->T; p.t_hi = a->t_hi; p.t_lo = a->t_lo;
-    p.x_dim = s->x_dim; p.cat_x = s->cat_x; p.cat_y_pred = s->cat_y_pred;
-    p.out_mode = a->out_mode; p.eps_only = 0;
-    return launch_sampler(s, p, (hipStream_t)stream);
-}
-
-extern "C" CARD_API int card_eps_theta(const card_sampler* s, const float* x, const float* y_t, const float* y_0_hat,
-                              int64_t N, int32_t t, float* out, void* stream) {
-    if (!s || !y_t || !y_0_hat || !out) return fail(CARD_E_INVALID, "card_eps_theta: null argument");
-    if (s->cat_x && s->x_dim > 0 && !x) return fail(CARD_E_INVALID, "card_eps_theta: x is NULL but the model concatenates x");
-    if (t < 0 || t >= s->n_embed) return fail(CARD_E_INVALID, "card_eps_theta: t=%d outside the gamma table", t);
-    if (N < 0) return fail(CARD_E_INVALID, "card_eps_theta: N < 0");
-    if (N == 0) return CARD_OK;
-    RunParams p;
-    memset(&p, 0, sizeof(p));
-    p.wpk = s->wpk; p.gtab = s->gtab; p.coef = nullptr; p.x = x; p.y0hat = y_0_hat; p.ytmean = y_0_hat;
-    p.y_init = y_t; p.noise = nullptr; p.out = out; p.N = N;
-    p.T = t + 1; p.t_hi = t; p.t_lo = t;
-    p.x_dim = s->x_dim; p.cat_x = s->cat_x; p.cat_y_pred = s->cat_y_pred;
-    p.out_mode = CARD_OUT_LAST; p.eps_only = 1;
-    return launch_sampler(s, p, (hipStream_t)stream);
-}
-
-extern "C" CARD_API int card_q_sample(const float* y, const float* y_0_hat, const float* sab, const float* somab,
-                             const int64_t* t, int64_t N, int32_t y_dim, int32_t T, const float* noise, uint64_t seed,
-                             uint64_t elem_offset, float* out, void* stream) {
-    (void)T;
-    if (!y || !y_0_hat || !sab || !somab || !t || !out) return fail(CARD_E_INVALID, "card_q_sample: null argument");
-    if (N < 0 || y_dim < 1) return fail(CARD_E_INVALID, "card_q_sample: bad N / y_dim");
-    if (N == 0) return CARD_OK;
-    const long long n = (long long)N * y_dim;
-    long long grid = (n + 255) / 256;
-    if (grid > 4096) grid = 4096;
-    q_sample_kernel<<<dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream>>>(y, y_0_hat, sab, somab, t, n, y_dim, noise, seed,
-                                                                                  elem_offset, out);
-    HIP_TRY(hipGetLastError());
-    return CARD_OK;
-}
-
-extern "C" CARD_API int card_philox_normal(uint64_t seed, uint64_t elem_offset, int64_t n_elems, int32_t draw0, int32_t n_draws,
-                                  float* out, void* stream) {
-    if (!out || n_elems < 0 || draw0 < 0 || n_draws < 0) return fail(CARD_E_INVALID, "card_philox_normal: bad argument");
-    if (n_elems == 0 || n_draws == 0) return CARD_OK;
-    long long grid = (n_elems + 255) / 256;
-    if (grid > 4096) grid = 4096;
-    philox_fill_kernel<<<dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream>>>(seed, elem_offset, n_elems, draw0, n_draws, out);
-    HIP_TRY(hipGetLastError());
     return CARD_OK;
 }

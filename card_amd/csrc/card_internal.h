@@ -1,0 +1,52 @@
+// card_internal.h - the sampler handle and the per-variant back ends behind the C ABI.
+#ifndef CARD_INTERNAL_H
+#define CARD_INTERNAL_H
+#include "card_common.h"
+
+// Launch-level arguments shared by both back ends (validated by card_sampler_run / card_eps_theta).
+struct CardRun {
+    const float* x;         // GUIDED: x (N, x_dim);  BN_HADAMARD: x_feat (N, F)
+    const float* y0hat;
+    const float* ytmean;
+    const float* y_init;
+    const float* coef;      // (T, 8)
+    const float* noise;
+    float* out;
+    const int* state_slot;
+    void* workspace;
+    unsigned long long workspace_bytes;
+    long long N;
+    unsigned long long seed, elem_offset;
+    int T, t_hi, t_lo, out_mode, eps_only;
+};
+
+struct card_sampler {
+    int variant, x_dim, y_dim, hidden, n_embed, cat_x, cat_y_pred;
+    int d_in;
+    int device, num_cu;
+    // ---- CARD_VARIANT_GUIDED (card_guided.hip)
+    int k1, hoist, nqs;
+    float* wpk;    // packed LDS image
+    float* gtab;   // (n_embed, 3, H) gamma * log2e [* bn_scale]
+    float* w1s;    // hoist: packed static columns of W1
+    float* ws;     // hoist: per-wave scratch slots (num_cu * 8 * 16 KB)
+    void (*kernel)(const struct GuidedParams);
+    size_t lds_bytes;
+    // ---- CARD_VARIANT_BN_HADAMARD (card_wide.hip)
+    float* W1;     // (F, d_in)
+    float* W2;     // (F, F)
+    float* W3;     // (F, F)
+    float* W4;     // (C, F)
+    float* bias;   // b1 | b2 | b3 (3F) then b4 (C)
+    float* shift;  // bn_shift * log2e, (3, F)
+};
+
+int guided_create(card_sampler* s, const card_model_desc* d, hipStream_t stream);
+void guided_destroy(card_sampler* s);
+int guided_run(const card_sampler* s, const CardRun& r, hipStream_t stream);
+
+int wide_create(card_sampler* s, const card_model_desc* d, hipStream_t stream);
+void wide_destroy(card_sampler* s);
+int wide_run(const card_sampler* s, const CardRun& r, hipStream_t stream);
+unsigned long long wide_workspace_bytes(const card_sampler* s, long long N);
+#endif

@@ -1,0 +1,370 @@
+// card_wide.hip - streaming-GEMM back end for CARD_VARIANT_BN_HADAMARD (classification ConditionalModel,
+// classification/model.py:79-94 after the hoisted encoder), any feature width F that is a multiple of 128
+// (128 toy/MNIST, 2048 FashionMNIST, 4096 CIFAR-10, 6144 CIFAR-100) and any class count C.
+//
+// F x F fp32 weights (64 MB at F = 4096) do not fit on chip, so one timestep is a short chain of launches
+// over all N chains, activations round-tripping through HBM (N x F fp32; ~0.4 GB at the CIFAR-10 test
+// shape, < 3 % of a step's time at 6 TB/s):
+//     wide_layer1_kernel : h1 = x_feat * softplus(BN1(gamma1[t] * (W1 . cat(y_t, y_0_hat) + b1)))     (K = 2C)
+//     wide_gemm_kernel   : h2 = softplus(BN2(gamma2[t] * (h1 . W2^T + b2)))        fp32 MFMA, fused epilogue
+//     wide_gemm_kernel   : h3 = softplus(BN3(gamma3[t] * (h2 . W3^T + b3)))
+//     wide_gemm_kernel   : eps = h3 . W4^T + b4      (W4 zero-padded to 128 rows: same kernel, bias epilogue)
+//     wide_update_kernel : posterior update of y_t (regression/diffusion_utils.py:83-89), noise, outputs
+// Eval-mode BatchNorm is the per-feature affine (scale, shift); scale and log2e are folded into the per-step
+// gamma table at create time, so the epilogue is xs = fma(acc + b, g'[t], shift'); h = ln2 * softplus_l2(xs).
+//
+// GEMM: out[M x Nout] = A[M x K] . W[Nout x K]^T, both operands K-contiguous.  128 x 128 x 32 block tile, 4
+// waves as 2 x 2, each wave 2 x 2 v_mfma_f32_32x32x2_f32 tiles (64 accumulator VGPRs); LDS tiles are
+// [128][32 + 4 pad] floats, so one ds_read_b128 at [row][8t + 4*(lane>>5)] feeds 4 consecutive MFMAs
+// (k order inside a tile is permuted identically for both operands) and is bank-conflict free; global->LDS is
+// register-staged one tile ahead (issue loads, compute, write the other stage, one barrier per tile).
+#include "card_internal.h"
+
+using namespace card;
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 4;
+constexpr int kStageFloats = (BM + BN) * LDT;
+constexpr int kGemmLds = 2 * kStageFloats * (int)sizeof(float);   // 73 728 B -> two blocks per CU
+
+enum { EPI_SOFTPLUS = 0, EPI_BIAS = 1 };
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void wide_gemm_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                           const float* __restrict__ bias, const float* __restrict__ g,
+                                                           const float* __restrict__ sh, float* __restrict__ out,
+                                                           long long M, int K, int ldo) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, hh = lane >> 5;
+    const long long m0 = (long long)blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    // staging map: 8 threads cover one 128-byte row segment, 32 rows per pass, 4 passes per operand
+    const int sr = tid >> 3, sc = (tid & 7) * 4;
+    const float* ap[4];
+    const float* wp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        long long r = m0 + sr + 32 * i;
+        if (r > M - 1) r = M - 1;                       // clamp: rows past M are computed but never stored
+        ap[i] = A + r * K + sc;
+        wp[i] = W + (long long)(n0 + sr + 32 * i) * K + sc;
+    }
+    f32x4 ra[4], rw[4];
+    auto g_load = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + kt * BK);
+            rw[i] = *reinterpret_cast<const f32x4*>(wp[i] + kt * BK);
+        }
+    };
+    auto s_store = [&](int st) {
+        float* As = sm + st * kStageFloats;
+        float* Ws = As + BM * LDT;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(As + (sr + 32 * i) * LDT + sc) = ra[i];
+            *reinterpret_cast<f32x4*>(Ws + (sr + 32 * i) * LDT + sc) = rw[i];
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    const int nk = K / BK;
+    g_load(0);
+    s_store(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) g_load(kt + 1);
+        const float* As = sm + (kt & 1) * kStageFloats + (wm * 64 + li) * LDT + 4 * hh;
+        const float* Ws = sm + (kt & 1) * kStageFloats + BM * LDT + (wn * 64 + li) * LDT + 4 * hh;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(As + 8 * t);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(As + 32 * LDT + 8 * t);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(Ws + 8 * t);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(Ws + 32 * LDT + 8 * t);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (more) s_store((kt + 1) & 1);
+        __syncthreads();
+    }
+    // epilogue: C/D map of the 32x32 tile: column = lane & 31 (feature), row = (r&3) + 8(r>>2) + 4(lane>>5) (chain)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int col = n0 + wn * 64 + b * 32 + li;
+        const float bb = bias[col];
+        float gg = 0.0f, ss = 0.0f;
+        if (EPI == EPI_SOFTPLUS) { gg = g[col]; ss = sh[col]; }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long row = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                float v = acc[a][b][r] + bb;
+                if (EPI == EPI_SOFTPLUS) v = kLn2 * softplus_l2(fmaf(v, gg, ss));
+                if (row < M) out[row * ldo + col] = v;
+            }
+        }
+    }
+}
+
+// h1[n][f] = x_feat[n][f] * softplus(BN1(gamma1[t][f] * (b1[f] + W1[f,:C].y[n] + W1[f,C:].y_0_hat[n])))
+// (classification/model.py:82-87).  One thread = 4 consecutive features of one chain.
+__global__ void wide_layer1_kernel(const float* __restrict__ y, const float* __restrict__ yhat,
+                                   const float* __restrict__ xfeat, const float* __restrict__ W1,
+                                   const float* __restrict__ b1, const float* __restrict__ g, const float* __restrict__ sh,
+                                   int C, int guidance, int F, long long N, float* __restrict__ h1) {
+    const int fq = F >> 2, d1 = guidance ? 2 * C : C;
+    const long long total = N * fq;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long n = idx / fq;
+        const int f0 = (int)(idx - n * fq) * 4;
+        float acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = b1[f0 + u];
+        for (int c = 0; c < d1; ++c) {
+            const float v = c < C ? y[n * C + c] : yhat[n * C + (c - C)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = fmaf(W1[(long long)(f0 + u) * d1 + c], v, acc[u]);
+        }
+        const f32x4 xf = *reinterpret_cast<const f32x4*>(xfeat + n * F + f0);
+        f32x4 o;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) o[u] = xf[u] * (kLn2 * softplus_l2(fmaf(acc[u], g[f0 + u], sh[f0 + u])));
+        *reinterpret_cast<f32x4*>(h1 + n * F + f0) = o;
+    }
+}
+
+// y_T = draw 0 + y_T_mean (classification/diffusion_utils.py:123-124)
+__global__ void wide_init_kernel(const float* __restrict__ mu, const float* __restrict__ noise, unsigned long long seed,
+                                 unsigned long long elem_offset, long long n_elems, float* __restrict__ y,
+                                 float* __restrict__ out, const int* __restrict__ state_slot, long long fixed_slot) {
+    const long long slot = state_slot ? (long long)state_slot[0] : fixed_slot;
+    float* out0 = slot >= 0 ? out + slot * n_elems : nullptr;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_elems;
+         i += (long long)gridDim.x * blockDim.x) {
+        float z;
+        if (noise) {
+            z = noise[i];
+        } else {
+            float zz[4];
+            philox_normal4(seed, elem_offset + (unsigned long long)i, 0u, zz);
+            z = zz[0];
+        }
+        const float v = z + mu[i];
+        y[i] = v;
+        if (out0) out0[i] = v;
+    }
+}
+
+// posterior update of every (chain, class) element for timestep t (classification/diffusion_utils.py:80-86, :98-100)
+__global__ void wide_update_kernel(const float* __restrict__ eps, int ld_eps, const float* __restrict__ mu,
+                                   const float* __restrict__ coef_row, const float* __restrict__ noise_d,
+                                   unsigned long long seed, unsigned long long elem_offset, int draw, int t, int C,
+                                   long long n_elems, float* __restrict__ y, float* __restrict__ out,
+                                   const int* __restrict__ state_slot, int state, long long fixed_slot) {
+    const long long slot = state_slot ? (long long)state_slot[state] : fixed_slot;
+    float* out_slot = slot >= 0 ? out + slot * n_elems : nullptr;
+    const float c_inv = coef_row[CARD_COEF_INV_SQRT_AB], c_om = coef_row[CARD_COEF_ONE_M_SQRT_AB];
+    const float c_s = coef_row[CARD_COEF_SOMAB], g0 = coef_row[CARD_COEF_G0], g1 = coef_row[CARD_COEF_G1];
+    const float g2 = coef_row[CARD_COEF_G2], sig = coef_row[CARD_COEF_SIGMA];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_elems;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / C;
+        const int c = (int)(i - n * C);
+        const float e = eps[n * ld_eps + c], m = mu[i], yy = y[i];
+        const float y0r = c_inv * ((yy - c_om * m) - e * c_s);
+        float v = y0r;
+        if (t >= 1) {
+            float z;
+            if (noise_d) {
+                z = noise_d[i];
+            } else {
+                float zz[4];
+                philox_normal4(seed, elem_offset + (unsigned long long)i, (uint32_t)draw >> 2, zz);
+                z = pick4(zz, draw & 3);
+            }
+            v = ((g0 * y0r + g1 * yy) + g2 * m) + sig * z;
+        }
+        y[i] = v;
+        if (out_slot) out_slot[i] = v;
+    }
+}
+
+__global__ void wide_copy_eps_kernel(const float* __restrict__ eps, int ld_eps, int C, long long n_elems,
+                                     float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_elems;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / C;
+        out[i] = eps[n * ld_eps + (int)(i - n * C)];
+    }
+}
+
+// create-time: gtab[t][l][f] = gamma_l[t][f] * bn_scale_l[f] * log2e ; shift'[l][f] = bn_shift_l[f] * log2e
+__global__ void wide_pack_gamma_kernel(const float* g1, const float* g2, const float* g3, const float* s1,
+                                       const float* s2, const float* s3, int n_embed, int F, float* __restrict__ gtab) {
+    const long long total = (long long)n_embed * 3 * F;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int f = (int)(idx % F), l = (int)((idx / F) % 3);
+        const long long t = idx / (3LL * F);
+        const float* g = l == 0 ? g1 : (l == 1 ? g2 : g3);
+        const float* s = l == 0 ? s1 : (l == 1 ? s2 : s3);
+        gtab[idx] = (g[t * F + f] * s[f]) * kLog2e;
+    }
+}
+
+__global__ void wide_scale_kernel(const float* __restrict__ in, float scale, long long n, float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = in[i] * scale;
+}
+
+inline unsigned grid_for(long long n, int block = 256, long long cap = 8192) {
+    long long g = (n + block - 1) / block;
+    return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+struct WideWs {
+    float *hA, *hB, *eps, *y;
+    size_t bytes;
+};
+WideWs carve(void* base, long long N, int F, int C, int Cpad) {
+    WideWs w;
+    size_t off = 0;
+    char* p = (char*)base;
+    w.hA = (float*)(p + off); off += align256((size_t)N * F * 4);
+    w.hB = (float*)(p + off); off += align256((size_t)N * F * 4);
+    w.eps = (float*)(p + off); off += align256((size_t)N * Cpad * 4);
+    w.y = (float*)(p + off); off += align256((size_t)N * C * 4);
+    w.bytes = off;
+    return w;
+}
+
+int gemm(int epi, const float* A, const float* W, const float* bias, const float* g, const float* sh, float* out,
+         long long M, int K, int Nout, int ldo, hipStream_t stream) {
+    dim3 grid((unsigned)(Nout / BN), (unsigned)((M + BM - 1) / BM));
+    if (epi == EPI_SOFTPLUS)
+        wide_gemm_kernel<EPI_SOFTPLUS><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, out, M, K, ldo);
+    else
+        wide_gemm_kernel<EPI_BIAS><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, out, M, K, ldo);
+    HIP_TRY(hipGetLastError());
+    return CARD_OK;
+}
+
+}  // namespace
+
+unsigned long long wide_workspace_bytes(const card_sampler* s, long long N) {
+    const int Cpad = (s->y_dim + BN - 1) / BN * BN;
+    return carve(nullptr, N, s->hidden, s->y_dim, Cpad).bytes;
+}
+
+int wide_create(card_sampler* s, const card_model_desc* d, hipStream_t stream) {
+    const int F = d->hidden, C = d->y_dim;
+    if (F < 128 || F % 128) return card_fail(CARD_E_UNSUPPORTED, "card_sampler_create: BN_HADAMARD hidden=%d must be a multiple of 128", F);
+    if (d->x_dim != F) return card_fail(CARD_E_INVALID, "card_sampler_create: BN_HADAMARD x_dim (%d) must equal hidden (%d): x is x_feat", d->x_dim, F);
+    for (int l = 0; l < 3; ++l)
+        if (!d->bn_scale[l] || !d->bn_shift[l]) return card_fail(CARD_E_INVALID, "card_sampler_create: BN_HADAMARD needs bn_scale/bn_shift (layer %d)", l + 1);
+    const int d1 = s->d_in, Cpad = (C + BN - 1) / BN * BN;
+    const size_t FF = (size_t)F * F;
+    HIP_TRY(hipMalloc(&s->W1, (size_t)F * d1 * 4));
+    HIP_TRY(hipMalloc(&s->W2, FF * 4));
+    HIP_TRY(hipMalloc(&s->W3, FF * 4));
+    HIP_TRY(hipMalloc(&s->W4, (size_t)Cpad * F * 4));
+    HIP_TRY(hipMalloc(&s->bias, (size_t)(3 * F + Cpad) * 4));
+    HIP_TRY(hipMalloc(&s->shift, (size_t)3 * F * 4));
+    HIP_TRY(hipMalloc(&s->gtab, (size_t)d->n_embed * 3 * F * 4));
+    HIP_TRY(hipFuncSetAttribute((const void*)wide_gemm_kernel<EPI_SOFTPLUS>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
+    HIP_TRY(hipFuncSetAttribute((const void*)wide_gemm_kernel<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
+    HIP_TRY(hipMemcpyAsync(s->W1, d->W[0], (size_t)F * d1 * 4, hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(s->W2, d->W[1], FF * 4, hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(s->W3, d->W[2], FF * 4, hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemsetAsync(s->W4, 0, (size_t)Cpad * F * 4, stream));
+    HIP_TRY(hipMemcpyAsync(s->W4, d->W4, (size_t)C * F * 4, hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemsetAsync(s->bias, 0, (size_t)(3 * F + Cpad) * 4, stream));
+    for (int l = 0; l < 3; ++l) {
+        HIP_TRY(hipMemcpyAsync(s->bias + (size_t)l * F, d->b[l], (size_t)F * 4, hipMemcpyDeviceToDevice, stream));
+        wide_scale_kernel<<<grid_for(F), 256, 0, stream>>>(d->bn_shift[l], kLog2e, F, s->shift + (size_t)l * F);
+    }
+    HIP_TRY(hipMemcpyAsync(s->bias + (size_t)3 * F, d->b4, (size_t)C * 4, hipMemcpyDeviceToDevice, stream));
+    wide_pack_gamma_kernel<<<grid_for((long long)d->n_embed * 3 * F), 256, 0, stream>>>(
+        d->gamma[0], d->gamma[1], d->gamma[2], d->bn_scale[0], d->bn_scale[1], d->bn_scale[2], d->n_embed, F, s->gtab);
+    HIP_TRY(hipGetLastError());
+    return CARD_OK;
+}
+
+void wide_destroy(card_sampler* s) {
+    float* bufs[] = {s->W1, s->W2, s->W3, s->W4, s->bias, s->shift, s->gtab};
+    for (float* b : bufs)
+        if (b) (void)hipFree(b);
+}
+
+int wide_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
+    const int F = s->hidden, C = s->y_dim, Cpad = (C + BN - 1) / BN * BN;
+    const long long N = r.N, ne = N * C;
+    const unsigned long long need = wide_workspace_bytes(s, N);
+    if (!r.workspace || r.workspace_bytes < need)
+        return card_fail(CARD_E_INVALID, "card_sampler_run: BN_HADAMARD needs a %llu-byte workspace (card_sampler_workspace_bytes), got %llu",
+                         need, r.workspace ? r.workspace_bytes : 0ULL);
+    if (((uintptr_t)r.workspace & 255) != 0) return card_fail(CARD_E_INVALID, "card_sampler_run: workspace must be 256-byte aligned");
+    const WideWs w = carve(r.workspace, N, F, C, Cpad);
+    const float* b1 = s->bias;
+    const float* b2 = s->bias + F;
+    const float* b3 = s->bias + 2 * (size_t)F;
+    const float* b4 = s->bias + 3 * (size_t)F;
+
+    auto forward = [&](const float* y, int t) -> int {
+        const float* g = s->gtab + (size_t)t * 3 * F;
+        wide_layer1_kernel<<<grid_for(N * (F / 4)), 256, 0, stream>>>(y, r.y0hat, r.x, s->W1, b1, g, s->shift, C,
+                                                                    s->cat_y_pred, F, N, w.hA);
+        HIP_TRY(hipGetLastError());
+        int rc;
+        if ((rc = gemm(EPI_SOFTPLUS, w.hA, s->W2, b2, g + F, s->shift + F, w.hB, N, F, F, F, stream))) return rc;
+        if ((rc = gemm(EPI_SOFTPLUS, w.hB, s->W3, b3, g + 2 * (size_t)F, s->shift + 2 * (size_t)F, w.hA, N, F, F, F, stream))) return rc;
+        return gemm(EPI_BIAS, w.hA, s->W4, b4, nullptr, nullptr, w.eps, N, F, Cpad, Cpad, stream);
+    };
+
+    if (r.eps_only) {
+        if (int rc = forward(r.y_init, r.t_hi)) return rc;
+        wide_copy_eps_kernel<<<grid_for(ne), 256, 0, stream>>>(w.eps, Cpad, C, ne, r.out);
+        HIP_TRY(hipGetLastError());
+        return CARD_OK;
+    }
+    const int T = r.T;
+    const int base = r.y_init ? (T - r.t_hi) : 0;          // first draw consumed / first state produced
+    // output slot of a state: fixed (CARD_OUT_ALL), looked up on the device (CARD_OUT_SELECT) or none
+    const int* sel = r.out_mode == CARD_OUT_SELECT ? r.state_slot : nullptr;
+    auto fixed = [&](int state) -> long long { return r.out_mode == CARD_OUT_ALL ? state - base : -1; };
+    if (r.y_init) {
+        HIP_TRY(hipMemcpyAsync(w.y, r.y_init, (size_t)ne * 4, hipMemcpyDeviceToDevice, stream));
+    } else {
+        wide_init_kernel<<<grid_for(ne), 256, 0, stream>>>(r.ytmean, r.noise, r.seed, r.elem_offset, ne, w.y, r.out, sel, fixed(0));
+        HIP_TRY(hipGetLastError());
+    }
+    for (int t = r.t_hi; t >= r.t_lo; --t) {
+        if (int rc = forward(w.y, t)) return rc;
+        const int draw = T - t;
+        const float* nz = (r.noise && t >= 1) ? r.noise + (long long)(draw - base) * ne : nullptr;
+        wide_update_kernel<<<grid_for(ne), 256, 0, stream>>>(w.eps, Cpad, r.ytmean, r.coef + (size_t)t * CARD_COEF_COLS, nz,
+                                                            r.seed, r.elem_offset, draw, t, C, ne, w.y, r.out, sel, T - t,
+                                                            fixed(T - t));
+        HIP_TRY(hipGetLastError());
+    }
+    if (r.out_mode == CARD_OUT_LAST) HIP_TRY(hipMemcpyAsync(r.out, w.y, (size_t)ne * 4, hipMemcpyDeviceToDevice, stream));
+    return CARD_OK;
+}

@@ -13,7 +13,8 @@ import torch
 
 from . import _lib
 from ._lib import CardError
-from .sampler import coef_on_device, make_coef_table, sampler_for, _dev_f32, _ptr, _stream, _require_cuda
+from .sampler import (coef_on_device, make_coef_table, sampler_for, x_features, _dev_f32, _ptr, _stream,
+                      _require_cuda)
 
 __all__ = ["make_beta_schedule", "extract", "q_sample", "p_sample", "p_sample_t_1to0", "p_sample_loop",
            "y_0_reparam"]
@@ -49,6 +50,11 @@ def extract(input, t, x):
     """regression/diffusion_utils.py:34-38 (kept for callers that import it; not used by the kernels)."""
     out = torch.gather(input, 0, t.to(input.device))
     return out.reshape(*([t.shape[0]] + [1] * (len(x.shape) - 1)))
+
+
+def _model_x(model, s, x):
+    """What the kernels take as `x`: x itself (regression) or the hoisted encoder features (classification)."""
+    return x_features(model, x) if s.variant == _lib.VARIANT_BN_HADAMARD else x
 
 
 def _fresh_seed():
@@ -89,7 +95,7 @@ def p_sample(model, x, y, y_0_hat, y_T_mean, t, alphas, one_minus_alphas_bar_sqr
         raise CardError(f"p_sample: t={t} outside [1, {T - 1}]")
     coef = coef_on_device(alphas, one_minus_alphas_bar_sqrt, T, s.device)
     seed = _fresh_seed() if (seed is None and noise is None) else int(seed or 0)
-    return s.run(x, y_0_hat, y_T_mean, coef, T, t_hi=t, t_lo=t, y_init=y, noise=noise, seed=seed,
+    return s.run(_model_x(model, s, x), y_0_hat, y_T_mean, coef, T, t_hi=t, t_lo=t, y_init=y, noise=noise, seed=seed,
                  elem_offset=elem_offset)
 
 
@@ -104,7 +110,7 @@ def p_sample_t_1to0(model, x, y, y_0_hat, y_T_mean, one_minus_alphas_bar_sqrt):
     """regression/diffusion_utils.py:94-104: the last step (timestep index 0), no noise."""
     s = sampler_for(model)
     coef = _coef_row(one_minus_alphas_bar_sqrt, 0).to(s.device)
-    return s.run(x, y_0_hat, y_T_mean, coef, 1, t_hi=0, t_lo=0, y_init=y)
+    return s.run(_model_x(model, s, x), y_0_hat, y_T_mean, coef, 1, t_hi=0, t_lo=0, y_init=y)
 
 
 def y_0_reparam(model, x, y, y_0_hat, y_T_mean, t, one_minus_alphas_bar_sqrt):
@@ -112,7 +118,7 @@ def y_0_reparam(model, x, y, y_0_hat, y_T_mean, t, one_minus_alphas_bar_sqrt):
     s = sampler_for(model)
     ti = int(t.reshape(-1)[0].item()) if torch.is_tensor(t) else int(t)
     c = _coef_row(one_minus_alphas_bar_sqrt, ti)[0]
-    eps = s.eps_theta(x, y, y_0_hat, ti)
+    eps = s.eps_theta(_model_x(model, s, x), y, y_0_hat, ti)
     yy, mu = _dev_f32(y, s.device), _dev_f32(y_T_mean, s.device)
     return float(c[0]) * (yy - float(c[1]) * mu - eps * float(c[2]))
 
@@ -130,6 +136,7 @@ def p_sample_loop(model, x, y_0_hat, y_T_mean, n_steps, alphas, one_minus_alphas
     coef = coef_on_device(alphas, one_minus_alphas_bar_sqrt, T, s.device)
     seed = _fresh_seed() if (seed is None and noise is None) else int(seed or 0)
     kw = dict(noise=noise, seed=seed, elem_offset=elem_offset)
+    x = _model_x(model, s, x)
     if states is not None:
         return s.run(x, y_0_hat, y_T_mean, coef, T, out_mode=_lib.OUT_SELECT, states=states, **kw)
     if only_last_sample:

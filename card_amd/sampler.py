@@ -108,6 +108,36 @@ class Sampler:
                    gamma=[sd[f"lin{i}.embed.weight"] for i in (1, 2, 3)], W4=sd["lin4.weight"], b4=sd["lin4.bias"],
                    device=device)
 
+    @classmethod
+    def from_cls_state_dict(cls, sd, *, guidance=True, bn_eps=1e-5, device):
+        """Classification ConditionalModel theta weights (classification/model.py:67-77): lin1..lin4 plus the
+        eval-mode BatchNorm1d layers unetnorm1..3 folded to per-feature (scale, shift).  `x` of run() is then
+        x_feat = norm(encoder_x(x)) (classification/model.py:80-81, step-invariant in eval mode)."""
+        W1 = sd["lin1.lin.weight"]
+        C, F = int(sd["lin4.weight"].shape[0]), int(W1.shape[0])
+        scale, shift = [], []
+        for i in (1, 2, 3):
+            w, b = sd[f"unetnorm{i}.weight"].float(), sd[f"unetnorm{i}.bias"].float()
+            mean, var = sd[f"unetnorm{i}.running_mean"].float(), sd[f"unetnorm{i}.running_var"].float()
+            sc = w / torch.sqrt(var + bn_eps)
+            scale.append(sc)
+            shift.append(b - mean * sc)
+        return cls(variant=_lib.VARIANT_BN_HADAMARD, x_dim=F, y_dim=C, hidden=F,
+                   n_embed=int(sd["lin1.embed.weight"].shape[0]), cat_x=False, cat_y_pred=guidance,
+                   W=[sd[f"lin{i}.lin.weight"] for i in (1, 2, 3)], b=[sd[f"lin{i}.lin.bias"] for i in (1, 2, 3)],
+                   gamma=[sd[f"lin{i}.embed.weight"] for i in (1, 2, 3)], W4=sd["lin4.weight"], b4=sd["lin4.bias"],
+                   bn_scale=scale, bn_shift=shift, device=device)
+
+    def _workspace(self, N):
+        """(tensor, ptr, bytes) scratch for N rows: card_sampler_workspace_bytes (0 bytes for GUIDED)."""
+        nb = C.c_uint64()
+        _lib.check(_lib.lib().card_sampler_workspace_bytes(self._h, N, C.byref(nb)), "card_sampler_workspace_bytes")
+        if nb.value == 0:
+            return None, C.c_void_p(0), 0
+        ws = torch.empty(nb.value + 256, dtype=torch.uint8, device=self.device)
+        ptr = (ws.data_ptr() + 255) & ~255
+        return ws, C.c_void_p(ptr), nb.value
+
     # ------------------------------------------------------------------------------------------
     def _prep(self, t, cols, name):
         if t is None:
@@ -161,6 +191,7 @@ class Sampler:
         a.coef, a.noise = _ptr(coef), _ptr(nz)
         a.seed, a.elem_offset = int(seed) & (2 ** 64 - 1), int(elem_offset)
         a.out, a.out_mode, a.state_slot = _ptr(out), out_mode, _ptr(slot)
+        ws, a.workspace, a.workspace_bytes = self._workspace(N)
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().card_sampler_run(self._h, C.byref(a), _stream(self.device)), "card_sampler_run")
         return out
@@ -173,9 +204,10 @@ class Sampler:
         xx = self._prep(x, self.x_dim, "x") if need_x else None
         N = int(y0.shape[0])
         out = torch.empty(N, self.y_dim, device=self.device, dtype=torch.float32)
+        ws, wptr, wbytes = self._workspace(N)
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().card_eps_theta(self._h, _ptr(xx), _ptr(yt), _ptr(y0), N, int(t), _ptr(out),
-                                                 _stream(self.device)), "card_eps_theta")
+                                                 wptr, wbytes, _stream(self.device)), "card_eps_theta")
         return out
 
 
@@ -196,6 +228,28 @@ def _is_guided(model):
         hasattr(model.lin1, "lin") and hasattr(model.lin1, "embed") and not hasattr(model, "unetnorm1")
 
 
+def _is_cls(model):
+    # classification/model.py:22 ConditionalModel: lin1..lin4 + unetnorm1..3 + encoder_x + norm
+    return all(hasattr(model, n) for n in ("lin1", "lin2", "lin3", "lin4", "unetnorm1", "unetnorm2", "unetnorm3",
+                                           "encoder_x", "norm"))
+
+
+_xfeat_cache = weakref.WeakKeyDictionary()
+
+
+def x_features(model, x):
+    """x_feat = norm(encoder_x(x)) (classification/model.py:80-81), computed ONCE per distinct x tensor instead
+    of once per timestep: in eval mode it does not depend on t or y.  Stock PyTorch-ROCm (out of scope to fuse)."""
+    key = (x.data_ptr(), x._version, tuple(x.shape), str(x.device)) + _fingerprint(model)
+    hit = _xfeat_cache.get(model)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    with torch.no_grad():
+        xf = model.norm(model.encoder_x(x)).float().contiguous()
+    _xfeat_cache[model] = (key, xf)
+    return xf
+
+
 def sampler_for(model):
     """The cached Sampler of an eps_theta `nn.Module` (raises for architectures the kernels do not cover)."""
     if getattr(model, "training", False):
@@ -210,8 +264,12 @@ def sampler_for(model):
     if _is_guided(model):
         s = Sampler.from_state_dict(model.state_dict(), cat_x=bool(model.cat_x), cat_y_pred=bool(model.cat_y_pred),
                                     device=device)
+    elif _is_cls(model):
+        s = Sampler.from_cls_state_dict(model.state_dict(), guidance=bool(getattr(model, "guidance", True)),
+                                        bn_eps=float(model.unetnorm1.eps), device=device)
     else:
         raise CardError(f"card_amd does not recognise {type(model).__name__} as a CARD eps_theta network "
-                        "(expected regression ConditionalGuidedModel); there is no eager fallback")
+                        "(expected regression ConditionalGuidedModel or classification ConditionalModel); "
+                        "there is no eager fallback")
     _cache[model] = (fp, s)
     return s

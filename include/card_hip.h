@@ -127,6 +127,9 @@ typedef struct card_run_args {
     float* out;             /* device, see card_out_mode */
     int32_t out_mode;
     const int32_t* state_slot; /* device (T+1) ints, CARD_OUT_SELECT only */
+    void* workspace;        /* device scratch, 256-byte aligned, card_sampler_workspace_bytes(s, N) bytes
+                               (BN_HADAMARD: activations between the per-step GEMMs; GUIDED needs none: NULL) */
+    uint64_t workspace_bytes;
 } card_run_args;
 
 /* Run timesteps t_hi ... t_lo of the reverse process for N independent chains in ONE persistent kernel.
@@ -135,11 +138,15 @@ typedef struct card_run_args {
  * p_sample_t_1to0 (:94-104) with t_hi = t_lo = 0. */
 CARD_API int card_sampler_run(const card_sampler* s, const card_run_args* args, void* stream);
 
+/* Scratch bytes card_sampler_run / card_eps_theta need for N rows (0 for GUIDED).  No reference counterpart:
+ * the reference lets PyTorch allocate its activations; here the caller owns them so that a run never allocates. */
+CARD_API int card_sampler_workspace_bytes(const card_sampler* s, int64_t N, uint64_t* bytes);
+
 /* eps_theta forward only: out (N, y_dim) = model(x, y_t, y_0_hat, t).
  * Replaces: ConditionalGuidedModel.forward (regression/model.py:37-51) /
  * ConditionalModel.forward after the encoder (classification/model.py:82-94). */
 CARD_API int card_eps_theta(const card_sampler* s, const float* x, const float* y_t, const float* y_0_hat, int64_t N,
-                   int32_t t, float* out, void* stream);
+                   int32_t t, float* out, void* workspace, uint64_t workspace_bytes, void* stream);
 
 /* Forward process sample, regression/diffusion_utils.py:42-53:
  * out = sqrt_ab[t_i]*y + (1 - sqrt_ab[t_i])*y_0_hat + somab[t_i]*noise, per-row t (device int64 (N,)).

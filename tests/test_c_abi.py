@@ -29,10 +29,21 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert _lib.lib().card_version() == 100
 
 
-def test_struct_sizes_match_header_layout():
-    # 8 int32 + 17 pointers; 4 int32 + int64 + 6 ptr + 2 u64 + ptr + int32(+pad) + ptr
-    assert ctypes.sizeof(_lib.ModelDesc) == 8 * 4 + 17 * 8
-    assert ctypes.sizeof(_lib.RunArgs) == 16 + 8 + 6 * 8 + 16 + 8 + 8 + 8
+def test_struct_sizes_match_header_layout(tmp_path):
+    """sizeof / offsetof of the ABI structs as gcc sees include/card_hip.h == the ctypes mirror in _lib.py."""
+    import subprocess
+    src = tmp_path / "sz.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "card_hip.h"\n'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(card_model_desc), sizeof(card_run_args),'
+        ' offsetof(card_model_desc, W), offsetof(card_run_args, N), offsetof(card_run_args, out_mode),'
+        ' offsetof(card_run_args, workspace_bytes)); return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    M, R = _lib.ModelDesc, _lib.RunArgs
+    assert got == [ctypes.sizeof(M), ctypes.sizeof(R), M.W.offset, R.N.offset, R.out_mode.offset,
+                   R.workspace_bytes.offset]
 
 
 def test_error_reporting_without_gpu():
