@@ -5,7 +5,7 @@
 // F x F fp32 weights (64 MB at F = 4096) do not fit on chip, so one timestep is a short chain of launches
 // over all N chains, activations round-tripping through HBM (N x F fp32; ~0.4 GB at the CIFAR-10 test
 // shape, < 3 % of a step's time at 6 TB/s):
-//     wide_layer1_kernel : h1 = x_feat * softplus(BN1(gamma1[t] * (W1 . cat(y_t, y_0_hat) + b1)))     (K = 2C)
+//     wide_gemm_kernel   : h1 = x_feat * softplus(BN1(gamma1[t] * (S . W1^T + b1))),  S = (y_t | y_0_hat | 0), K = 2C -> 32
 //     wide_gemm_kernel   : h2 = softplus(BN2(gamma2[t] * (h1 . W2^T + b2)))        fp32 MFMA, fused epilogue
 //     wide_gemm_kernel   : h3 = softplus(BN3(gamma3[t] * (h2 . W3^T + b3)))
 //     wide_gemm_kernel   : eps = h3 . W4^T + b4      (W4 zero-padded to 128 rows: same kernel, bias epilogue)
@@ -28,13 +28,13 @@ constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 4;
 constexpr int kStageFloats = (BM + BN) * LDT;
 constexpr int kGemmLds = 2 * kStageFloats * (int)sizeof(float);   // 73 728 B -> two blocks per CU
 
-enum { EPI_SOFTPLUS = 0, EPI_BIAS = 1 };
+enum { EPI_SOFTPLUS = 0, EPI_BIAS = 1, EPI_SOFTPLUS_MUL = 2 };
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void wide_gemm_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                            const float* __restrict__ bias, const float* __restrict__ g,
-                                                           const float* __restrict__ sh, float* __restrict__ out,
-                                                           long long M, int K, int ldo) {
+                                                           const float* __restrict__ sh, const float* __restrict__ mul,
+                                                           float* __restrict__ out, long long M, int K, int ldo) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, hh = lane >> 5;
@@ -108,52 +108,46 @@ __global__ __launch_bounds__(256, 2) void wide_gemm_kernel(const float* __restri
         const int col = n0 + wn * 64 + b * 32 + li;
         const float bb = bias[col];
         float gg = 0.0f, ss = 0.0f;
-        if (EPI == EPI_SOFTPLUS) { gg = g[col]; ss = sh[col]; }
+        if (EPI != EPI_BIAS) { gg = g[col]; ss = sh[col]; }
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const long long row = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                 float v = acc[a][b][r] + bb;
-                if (EPI == EPI_SOFTPLUS) v = kLn2 * softplus_l2(fmaf(v, gg, ss));
-                if (row < M) out[row * ldo + col] = v;
+                if (EPI != EPI_BIAS) v = kLn2 * softplus_l2(fmaf(v, gg, ss));
+                if (row < M) {
+                    if (EPI == EPI_SOFTPLUS_MUL) v *= mul[row * ldo + col];     // Hadamard with x_feat (model.py:87)
+                    out[row * ldo + col] = v;
+                }
             }
         }
     }
 }
 
-// h1[n][f] = x_feat[n][f] * softplus(BN1(gamma1[t][f] * (b1[f] + W1[f,:C].y[n] + W1[f,C:].y_0_hat[n])))
-// (classification/model.py:82-87).  One thread = 4 consecutive features of one chain.
-__global__ void wide_layer1_kernel(const float* __restrict__ y, const float* __restrict__ yhat,
-                                   const float* __restrict__ xfeat, const float* __restrict__ W1,
-                                   const float* __restrict__ b1, const float* __restrict__ g, const float* __restrict__ sh,
-                                   int C, int guidance, int F, long long N, float* __restrict__ h1) {
-    const int fq = F >> 2, d1 = guidance ? 2 * C : C;
-    const long long total = N * fq;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const long long n = idx / fq;
-        const int f0 = (int)(idx - n * fq) * 4;
-        float acc[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] = b1[f0 + u];
-        for (int c = 0; c < d1; ++c) {
-            const float v = c < C ? y[n * C + c] : yhat[n * C + (c - C)];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc[u] = fmaf(W1[(long long)(f0 + u) * d1 + c], v, acc[u]);
+// Layer 1 (classification/model.py:82-87) is the same GEMM with K = Kp = 2C padded to a multiple of 32: its A
+// operand is the state matrix S (N x Kp): columns [0, C) hold y_t (rewritten every step by the update kernel),
+// columns [C, 2C) hold y_0_hat (guidance), the rest is zero.  This kernel writes the static columns once per run
+// and, when y_src is given, the y_t columns too.
+__global__ void wide_pack_state_kernel(const float* __restrict__ y_src, const float* __restrict__ yhat, int C,
+                                       int guidance, int Kp, long long N, float* __restrict__ S) {
+    const long long total = N * Kp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / Kp;
+        const int k = (int)(i - n * Kp);
+        if (k < C) {
+            if (y_src) S[i] = y_src[n * C + k];
+        } else {
+            S[i] = (guidance && k < 2 * C) ? yhat[n * C + (k - C)] : 0.0f;
         }
-        const f32x4 xf = *reinterpret_cast<const f32x4*>(xfeat + n * F + f0);
-        f32x4 o;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) o[u] = xf[u] * (kLn2 * softplus_l2(fmaf(acc[u], g[f0 + u], sh[f0 + u])));
-        *reinterpret_cast<f32x4*>(h1 + n * F + f0) = o;
     }
 }
 
 // y_T = draw 0 + y_T_mean (classification/diffusion_utils.py:123-124)
 __global__ void wide_init_kernel(const float* __restrict__ mu, const float* __restrict__ noise, unsigned long long seed,
-                                 unsigned long long elem_offset, long long n_elems, float* __restrict__ y,
-                                 float* __restrict__ out, const int* __restrict__ state_slot, long long fixed_slot) {
+                                 unsigned long long elem_offset, long long n_elems, int C, int Kp,
+                                 float* __restrict__ S, float* __restrict__ out, const int* __restrict__ state_slot,
+                                 long long fixed_slot) {
     const long long slot = state_slot ? (long long)state_slot[0] : fixed_slot;
     float* out0 = slot >= 0 ? out + slot * n_elems : nullptr;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_elems;
@@ -167,7 +161,8 @@ __global__ void wide_init_kernel(const float* __restrict__ mu, const float* __re
             z = zz[0];
         }
         const float v = z + mu[i];
-        y[i] = v;
+        const long long n = i / C;
+        S[n * Kp + (int)(i - n * C)] = v;
         if (out0) out0[i] = v;
     }
 }
@@ -176,7 +171,7 @@ __global__ void wide_init_kernel(const float* __restrict__ mu, const float* __re
 __global__ void wide_update_kernel(const float* __restrict__ eps, int ld_eps, const float* __restrict__ mu,
                                    const float* __restrict__ coef_row, const float* __restrict__ noise_d,
                                    unsigned long long seed, unsigned long long elem_offset, int draw, int t, int C,
-                                   long long n_elems, float* __restrict__ y, float* __restrict__ out,
+                                   long long n_elems, int Kp, float* __restrict__ S, float* __restrict__ out,
                                    const int* __restrict__ state_slot, int state, long long fixed_slot) {
     const long long slot = state_slot ? (long long)state_slot[state] : fixed_slot;
     float* out_slot = slot >= 0 ? out + slot * n_elems : nullptr;
@@ -187,7 +182,7 @@ __global__ void wide_update_kernel(const float* __restrict__ eps, int ld_eps, co
          i += (long long)gridDim.x * blockDim.x) {
         const long long n = i / C;
         const int c = (int)(i - n * C);
-        const float e = eps[n * ld_eps + c], m = mu[i], yy = y[i];
+        const float e = eps[n * ld_eps + c], m = mu[i], yy = S[n * Kp + c];
         const float y0r = c_inv * ((yy - c_om * m) - e * c_s);
         float v = y0r;
         if (t >= 1) {
@@ -201,7 +196,7 @@ __global__ void wide_update_kernel(const float* __restrict__ eps, int ld_eps, co
             }
             v = ((g0 * y0r + g1 * yy) + g2 * m) + sig * z;
         }
-        y[i] = v;
+        S[n * Kp + c] = v;
         if (out_slot) out_slot[i] = v;
     }
 }
@@ -229,6 +224,16 @@ __global__ void wide_pack_gamma_kernel(const float* g1, const float* g2, const f
     }
 }
 
+// (rows x cols) -> (rows x ldp), zero padded
+__global__ void wide_pad_cols_kernel(const float* __restrict__ in, int rows, int cols, int ldp, float* __restrict__ out) {
+    const long long total = (long long)rows * ldp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / ldp;
+        const int c = (int)(i - r * ldp);
+        out[i] = c < cols ? in[r * cols + c] : 0.0f;
+    }
+}
+
 __global__ void wide_scale_kernel(const float* __restrict__ in, float scale, long long n, float* __restrict__ out) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         out[i] = in[i] * scale;
@@ -240,29 +245,33 @@ inline unsigned grid_for(long long n, int block = 256, long long cap = 8192) {
 }
 inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
+inline int state_ld(const card_sampler* s) { return (s->d_in + BK - 1) / BK * BK; }
+
 struct WideWs {
-    float *hA, *hB, *eps, *y;
+    float *hA, *hB, *eps, *S;
     size_t bytes;
 };
-WideWs carve(void* base, long long N, int F, int C, int Cpad) {
+WideWs carve(void* base, long long N, int F, int Kp, int Cpad) {
     WideWs w;
     size_t off = 0;
     char* p = (char*)base;
     w.hA = (float*)(p + off); off += align256((size_t)N * F * 4);
     w.hB = (float*)(p + off); off += align256((size_t)N * F * 4);
     w.eps = (float*)(p + off); off += align256((size_t)N * Cpad * 4);
-    w.y = (float*)(p + off); off += align256((size_t)N * C * 4);
+    w.S = (float*)(p + off); off += align256((size_t)N * Kp * 4);
     w.bytes = off;
     return w;
 }
 
-int gemm(int epi, const float* A, const float* W, const float* bias, const float* g, const float* sh, float* out,
-         long long M, int K, int Nout, int ldo, hipStream_t stream) {
+int gemm(int epi, const float* A, const float* W, const float* bias, const float* g, const float* sh, const float* mul,
+         float* out, long long M, int K, int Nout, int ldo, hipStream_t stream) {
     dim3 grid((unsigned)(Nout / BN), (unsigned)((M + BM - 1) / BM));
     if (epi == EPI_SOFTPLUS)
-        wide_gemm_kernel<EPI_SOFTPLUS><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, out, M, K, ldo);
+        wide_gemm_kernel<EPI_SOFTPLUS><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, out, M, K, ldo);
+    else if (epi == EPI_SOFTPLUS_MUL)
+        wide_gemm_kernel<EPI_SOFTPLUS_MUL><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, out, M, K, ldo);
     else
-        wide_gemm_kernel<EPI_BIAS><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, out, M, K, ldo);
+        wide_gemm_kernel<EPI_BIAS><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, out, M, K, ldo);
     HIP_TRY(hipGetLastError());
     return CARD_OK;
 }
@@ -271,7 +280,7 @@ int gemm(int epi, const float* A, const float* W, const float* bias, const float
 
 unsigned long long wide_workspace_bytes(const card_sampler* s, long long N) {
     const int Cpad = (s->y_dim + BN - 1) / BN * BN;
-    return carve(nullptr, N, s->hidden, s->y_dim, Cpad).bytes;
+    return carve(nullptr, N, s->hidden, state_ld(s), Cpad).bytes;
 }
 
 int wide_create(card_sampler* s, const card_model_desc* d, hipStream_t stream) {
@@ -282,7 +291,8 @@ int wide_create(card_sampler* s, const card_model_desc* d, hipStream_t stream) {
         if (!d->bn_scale[l] || !d->bn_shift[l]) return card_fail(CARD_E_INVALID, "card_sampler_create: BN_HADAMARD needs bn_scale/bn_shift (layer %d)", l + 1);
     const int d1 = s->d_in, Cpad = (C + BN - 1) / BN * BN;
     const size_t FF = (size_t)F * F;
-    HIP_TRY(hipMalloc(&s->W1, (size_t)F * d1 * 4));
+    const int Kp = state_ld(s);
+    HIP_TRY(hipMalloc(&s->W1, (size_t)F * Kp * 4));
     HIP_TRY(hipMalloc(&s->W2, FF * 4));
     HIP_TRY(hipMalloc(&s->W3, FF * 4));
     HIP_TRY(hipMalloc(&s->W4, (size_t)Cpad * F * 4));
@@ -291,7 +301,8 @@ int wide_create(card_sampler* s, const card_model_desc* d, hipStream_t stream) {
     HIP_TRY(hipMalloc(&s->gtab, (size_t)d->n_embed * 3 * F * 4));
     HIP_TRY(hipFuncSetAttribute((const void*)wide_gemm_kernel<EPI_SOFTPLUS>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
     HIP_TRY(hipFuncSetAttribute((const void*)wide_gemm_kernel<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
-    HIP_TRY(hipMemcpyAsync(s->W1, d->W[0], (size_t)F * d1 * 4, hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipFuncSetAttribute((const void*)wide_gemm_kernel<EPI_SOFTPLUS_MUL>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
+    wide_pad_cols_kernel<<<grid_for((long long)F * Kp), 256, 0, stream>>>(d->W[0], F, d1, Kp, s->W1);
     HIP_TRY(hipMemcpyAsync(s->W2, d->W[1], FF * 4, hipMemcpyDeviceToDevice, stream));
     HIP_TRY(hipMemcpyAsync(s->W3, d->W[2], FF * 4, hipMemcpyDeviceToDevice, stream));
     HIP_TRY(hipMemsetAsync(s->W4, 0, (size_t)Cpad * F * 4, stream));
@@ -322,25 +333,28 @@ int wide_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
         return card_fail(CARD_E_INVALID, "card_sampler_run: BN_HADAMARD needs a %llu-byte workspace (card_sampler_workspace_bytes), got %llu",
                          need, r.workspace ? r.workspace_bytes : 0ULL);
     if (((uintptr_t)r.workspace & 255) != 0) return card_fail(CARD_E_INVALID, "card_sampler_run: workspace must be 256-byte aligned");
-    const WideWs w = carve(r.workspace, N, F, C, Cpad);
+    const int Kp = state_ld(s);
+    const WideWs w = carve(r.workspace, N, F, Kp, Cpad);
     const float* b1 = s->bias;
     const float* b2 = s->bias + F;
     const float* b3 = s->bias + 2 * (size_t)F;
     const float* b4 = s->bias + 3 * (size_t)F;
 
-    auto forward = [&](const float* y, int t) -> int {
+    // one eps_theta forward from the state matrix S (y_t | y_0_hat | 0) at timestep t -> w.eps (N x Cpad)
+    auto forward = [&](int t) -> int {
         const float* g = s->gtab + (size_t)t * 3 * F;
-        wide_layer1_kernel<<<grid_for(N * (F / 4)), 256, 0, stream>>>(y, r.y0hat, r.x, s->W1, b1, g, s->shift, C,
-                                                                    s->cat_y_pred, F, N, w.hA);
-        HIP_TRY(hipGetLastError());
         int rc;
-        if ((rc = gemm(EPI_SOFTPLUS, w.hA, s->W2, b2, g + F, s->shift + F, w.hB, N, F, F, F, stream))) return rc;
-        if ((rc = gemm(EPI_SOFTPLUS, w.hB, s->W3, b3, g + 2 * (size_t)F, s->shift + 2 * (size_t)F, w.hA, N, F, F, F, stream))) return rc;
-        return gemm(EPI_BIAS, w.hA, s->W4, b4, nullptr, nullptr, w.eps, N, F, Cpad, Cpad, stream);
+        if ((rc = gemm(EPI_SOFTPLUS_MUL, w.S, s->W1, b1, g, s->shift, r.x, w.hA, N, Kp, F, F, stream))) return rc;
+        if ((rc = gemm(EPI_SOFTPLUS, w.hA, s->W2, b2, g + F, s->shift + F, nullptr, w.hB, N, F, F, F, stream))) return rc;
+        if ((rc = gemm(EPI_SOFTPLUS, w.hB, s->W3, b3, g + 2 * (size_t)F, s->shift + 2 * (size_t)F, nullptr, w.hA, N, F, F, F, stream))) return rc;
+        return gemm(EPI_BIAS, w.hA, s->W4, b4, nullptr, nullptr, nullptr, w.eps, N, F, Cpad, Cpad, stream);
     };
+    // static columns of S (+ y_t when the caller supplies it)
+    wide_pack_state_kernel<<<grid_for(N * Kp), 256, 0, stream>>>(r.y_init, r.y0hat, C, s->cat_y_pred, Kp, N, w.S);
+    HIP_TRY(hipGetLastError());
 
     if (r.eps_only) {
-        if (int rc = forward(r.y_init, r.t_hi)) return rc;
+        if (int rc = forward(r.t_hi)) return rc;
         wide_copy_eps_kernel<<<grid_for(ne), 256, 0, stream>>>(w.eps, Cpad, C, ne, r.out);
         HIP_TRY(hipGetLastError());
         return CARD_OK;
@@ -350,21 +364,23 @@ int wide_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     // output slot of a state: fixed (CARD_OUT_ALL), looked up on the device (CARD_OUT_SELECT) or none
     const int* sel = r.out_mode == CARD_OUT_SELECT ? r.state_slot : nullptr;
     auto fixed = [&](int state) -> long long { return r.out_mode == CARD_OUT_ALL ? state - base : -1; };
-    if (r.y_init) {
-        HIP_TRY(hipMemcpyAsync(w.y, r.y_init, (size_t)ne * 4, hipMemcpyDeviceToDevice, stream));
-    } else {
-        wide_init_kernel<<<grid_for(ne), 256, 0, stream>>>(r.ytmean, r.noise, r.seed, r.elem_offset, ne, w.y, r.out, sel, fixed(0));
+    if (!r.y_init) {
+        wide_init_kernel<<<grid_for(ne), 256, 0, stream>>>(r.ytmean, r.noise, r.seed, r.elem_offset, ne, C, Kp, w.S, r.out,
+                                                          sel, fixed(0));
         HIP_TRY(hipGetLastError());
     }
     for (int t = r.t_hi; t >= r.t_lo; --t) {
-        if (int rc = forward(w.y, t)) return rc;
+        if (int rc = forward(t)) return rc;
         const int draw = T - t;
         const float* nz = (r.noise && t >= 1) ? r.noise + (long long)(draw - base) * ne : nullptr;
         wide_update_kernel<<<grid_for(ne), 256, 0, stream>>>(w.eps, Cpad, r.ytmean, r.coef + (size_t)t * CARD_COEF_COLS, nz,
-                                                            r.seed, r.elem_offset, draw, t, C, ne, w.y, r.out, sel, T - t,
+                                                            r.seed, r.elem_offset, draw, t, C, ne, Kp, w.S, r.out, sel, T - t,
                                                             fixed(T - t));
         HIP_TRY(hipGetLastError());
     }
-    if (r.out_mode == CARD_OUT_LAST) HIP_TRY(hipMemcpyAsync(r.out, w.y, (size_t)ne * 4, hipMemcpyDeviceToDevice, stream));
+    if (r.out_mode == CARD_OUT_LAST) {
+        wide_copy_eps_kernel<<<grid_for(ne), 256, 0, stream>>>(w.S, Kp, C, ne, r.out);   // y_t columns of S -> (N, C)
+        HIP_TRY(hipGetLastError());
+    }
     return CARD_OK;
 }
