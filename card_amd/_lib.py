@@ -32,7 +32,7 @@ class RunArgs(C.Structure):
         ("struct_bytes", C.c_int32), ("T", C.c_int32), ("t_hi", C.c_int32), ("t_lo", C.c_int32),
         ("N", C.c_int64), ("x", _fp), ("y_0_hat", _fp), ("y_T_mean", _fp), ("y_init", _fp), ("coef", _fp),
         ("noise", _fp), ("seed", C.c_uint64), ("elem_offset", C.c_uint64), ("out", _fp),
-        ("out_mode", C.c_int32), ("state_slot", _fp), ("workspace", _fp), ("workspace_bytes", C.c_uint64),
+        ("out_mode", C.c_int32), ("n_z", C.c_int32), ("state_slot", _fp), ("workspace", _fp), ("workspace_bytes", C.c_uint64),
     ]
 
 

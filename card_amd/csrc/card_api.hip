@@ -155,6 +155,8 @@ extern "C" CARD_API int card_sampler_run(const card_sampler* s, const card_run_a
     const bool need_x = s->variant == CARD_VARIANT_BN_HADAMARD || (s->cat_x && s->x_dim > 0);
     if (need_x && !a->x) return fail(CARD_E_INVALID, "card_sampler_run: x is NULL but the model reads x");
     if (a->out_mode == CARD_OUT_SELECT && !a->state_slot) return fail(CARD_E_INVALID, "card_sampler_run: CARD_OUT_SELECT needs state_slot");
+    if (a->n_z < 0 || (a->n_z > 1 && a->N % a->n_z != 0))
+        return fail(CARD_E_INVALID, "card_sampler_run: N=%lld is not a multiple of n_z=%d", (long long)a->N, a->n_z);
     CardRun r;
     memset(&r, 0, sizeof(r));
     r.x = a->x; r.y0hat = a->y_0_hat; r.ytmean = a->y_T_mean; r.y_init = a->y_init; r.coef = a->coef;
@@ -162,6 +164,7 @@ extern "C" CARD_API int card_sampler_run(const card_sampler* s, const card_run_a
     r.workspace = a->workspace; r.workspace_bytes = a->workspace_bytes;
     r.N = a->N; r.seed = a->seed; r.elem_offset = a->elem_offset;
     r.T = a->T; r.t_hi = a->t_hi; r.t_lo = a->t_lo; r.out_mode = a->out_mode; r.eps_only = 0;
+    r.n_z = a->n_z > 1 ? a->n_z : 1;
     return s->variant == CARD_VARIANT_GUIDED ? guided_run(s, r, (hipStream_t)stream) : wide_run(s, r, (hipStream_t)stream);
 }
 
@@ -178,7 +181,7 @@ extern "C" CARD_API int card_eps_theta(const card_sampler* s, const float* x, co
     memset(&r, 0, sizeof(r));
     r.x = x; r.y0hat = y_0_hat; r.ytmean = y_0_hat; r.y_init = y_t; r.out = out; r.N = N;
     r.workspace = workspace; r.workspace_bytes = workspace_bytes;
-    r.T = t + 1; r.t_hi = t; r.t_lo = t; r.out_mode = CARD_OUT_LAST; r.eps_only = 1;
+    r.T = t + 1; r.t_hi = t; r.t_lo = t; r.out_mode = CARD_OUT_LAST; r.eps_only = 1; r.n_z = 1;
     return s->variant == CARD_VARIANT_GUIDED ? guided_run(s, r, (hipStream_t)stream) : wide_run(s, r, (hipStream_t)stream);
 }
 

@@ -62,6 +62,7 @@ struct GuidedParams {
     int x_dim, cat_x, cat_y_pred;
     int out_mode;
     int eps_only;         // write eps_theta(y_init, t_hi) and stop
+    int n_z;              // chains per input row (x, y_0_hat, y_T_mean are indexed by chain / n_z)
     // hoisted layer 1 (HOIST kernels): static columns of W1 in fragment order + per-wave scratch slots
     const float* w1s;     // (4, nqs, 64, 4): W1[32j + (l&31)][1 + 8q + 2e + (l>>5)]
     float* ws;            // grid * 8 waves * 4096 floats
@@ -198,15 +199,16 @@ __global__ __launch_bounds__(kThreads, 2) void card_sample_guided_kernel(const R
         const long long row = p.n_begin + tile * kTileM + m;
         const bool valid = row < p.n_end;
         const long long rc = valid ? row : p.n_end - 1;
-        const float mu = p.ytmean[rc];
-        const float y0h = p.y0hat[rc];
+        const long long rr = p.n_z > 1 ? rc / p.n_z : rc;     // input row of this chain
+        const float mu = p.ytmean[rr];
+        const float y0h = p.y0hat[rr];
         const unsigned long long elem = p.elem_offset + (unsigned long long)rc;
 
         // feature k of cat(y_t, y_0_hat, x) (regression/model.py:38-47) for this lane's chain; k >= 1 is static
         auto static_feature = [&](int k) -> float {
             if (p.cat_y_pred && k == 1) return y0h;
             const int xi = k - 1 - (p.cat_y_pred ? 1 : 0);
-            return (p.cat_x && xi < p.x_dim) ? p.x[rc * p.x_dim + xi] : 0.0f;
+            return (p.cat_x && xi < p.x_dim) ? p.x[rr * p.x_dim + xi] : 0.0f;
         };
         // layer-1 input in B-operand order: k-step r takes feature 2r (lanes 0-31) and 2r+1 (lanes 32-63);
         // feature 0 (y_t) is rewritten every step.
@@ -460,7 +462,7 @@ int guided_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     p.N = r.N; p.seed = r.seed; p.elem_offset = r.elem_offset;
     p.T = r.T; p.t_hi = r.t_hi; p.t_lo = r.t_lo;
     p.x_dim = s->x_dim; p.cat_x = s->cat_x; p.cat_y_pred = s->cat_y_pred;
-    p.out_mode = r.out_mode; p.eps_only = r.eps_only;
+    p.out_mode = r.out_mode; p.eps_only = r.eps_only; p.n_z = r.n_z;
     p.w1s = s->w1s; p.ws = s->ws; p.nqs = s->nqs;
     // Split very large N into launches of whole waves-worth of tiles so that one launch stays well under
     // a second and every wave gets the same number of tiles (no intra-launch tail except in the last one).

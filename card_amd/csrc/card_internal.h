@@ -18,6 +18,7 @@ struct CardRun {
     long long N;
     unsigned long long seed, elem_offset;
     int T, t_hi, t_lo, out_mode, eps_only;
+    int n_z;                // >= 1: chains per input row
 };
 
 struct card_sampler {

@@ -34,7 +34,8 @@ template <int EPI>
 __global__ __launch_bounds__(256, 2) void wide_gemm_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                            const float* __restrict__ bias, const float* __restrict__ g,
                                                            const float* __restrict__ sh, const float* __restrict__ mul,
-                                                           float* __restrict__ out, long long M, int K, int ldo) {
+                                                           int mul_div, float* __restrict__ out, long long M, int K,
+                                                           int ldo) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, hh = lane >> 5;
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void wide_gemm_kernel(const float* __restri
                 float v = acc[a][b][r] + bb;
                 if (EPI != EPI_BIAS) v = kLn2 * softplus_l2(fmaf(v, gg, ss));
                 if (row < M) {
-                    if (EPI == EPI_SOFTPLUS_MUL) v *= mul[row * ldo + col];     // Hadamard with x_feat (model.py:87)
+                    if (EPI == EPI_SOFTPLUS_MUL) v *= mul[(row / mul_div) * ldo + col];   // Hadamard with x_feat (model.py:87)
                     out[row * ldo + col] = v;
                 }
             }
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void wide_gemm_kernel(const float* __restri
 // columns [C, 2C) hold y_0_hat (guidance), the rest is zero.  This kernel writes the static columns once per run
 // and, when y_src is given, the y_t columns too.
 __global__ void wide_pack_state_kernel(const float* __restrict__ y_src, const float* __restrict__ yhat, int C,
-                                       int guidance, int Kp, long long N, float* __restrict__ S) {
+                                       int guidance, int Kp, int n_z, long long N, float* __restrict__ S) {
     const long long total = N * Kp;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long n = i / Kp;
@@ -138,14 +139,14 @@ __global__ void wide_pack_state_kernel(const float* __restrict__ y_src, const fl
         if (k < C) {
             if (y_src) S[i] = y_src[n * C + k];
         } else {
-            S[i] = (guidance && k < 2 * C) ? yhat[n * C + (k - C)] : 0.0f;
+            S[i] = (guidance && k < 2 * C) ? yhat[(n / n_z) * C + (k - C)] : 0.0f;
         }
     }
 }
 
 // y_T = draw 0 + y_T_mean (classification/diffusion_utils.py:123-124)
 __global__ void wide_init_kernel(const float* __restrict__ mu, const float* __restrict__ noise, unsigned long long seed,
-                                 unsigned long long elem_offset, long long n_elems, int C, int Kp,
+                                 unsigned long long elem_offset, long long n_elems, int C, int Kp, int n_z,
                                  float* __restrict__ S, float* __restrict__ out, const int* __restrict__ state_slot,
                                  long long fixed_slot) {
     const long long slot = state_slot ? (long long)state_slot[0] : fixed_slot;
@@ -160,9 +161,10 @@ __global__ void wide_init_kernel(const float* __restrict__ mu, const float* __re
             philox_normal4(seed, elem_offset + (unsigned long long)i, 0u, zz);
             z = zz[0];
         }
-        const float v = z + mu[i];
         const long long n = i / C;
-        S[n * Kp + (int)(i - n * C)] = v;
+        const int c = (int)(i - n * C);
+        const float v = z + mu[(n / n_z) * C + c];
+        S[n * Kp + c] = v;
         if (out0) out0[i] = v;
     }
 }
@@ -171,7 +173,7 @@ __global__ void wide_init_kernel(const float* __restrict__ mu, const float* __re
 __global__ void wide_update_kernel(const float* __restrict__ eps, int ld_eps, const float* __restrict__ mu,
                                    const float* __restrict__ coef_row, const float* __restrict__ noise_d,
                                    unsigned long long seed, unsigned long long elem_offset, int draw, int t, int C,
-                                   long long n_elems, int Kp, float* __restrict__ S, float* __restrict__ out,
+                                   long long n_elems, int Kp, int n_z, float* __restrict__ S, float* __restrict__ out,
                                    const int* __restrict__ state_slot, int state, long long fixed_slot) {
     const long long slot = state_slot ? (long long)state_slot[state] : fixed_slot;
     float* out_slot = slot >= 0 ? out + slot * n_elems : nullptr;
@@ -182,7 +184,7 @@ __global__ void wide_update_kernel(const float* __restrict__ eps, int ld_eps, co
          i += (long long)gridDim.x * blockDim.x) {
         const long long n = i / C;
         const int c = (int)(i - n * C);
-        const float e = eps[n * ld_eps + c], m = mu[i], yy = S[n * Kp + c];
+        const float e = eps[n * ld_eps + c], m = mu[(n / n_z) * C + c], yy = S[n * Kp + c];
         const float y0r = c_inv * ((yy - c_om * m) - e * c_s);
         float v = y0r;
         if (t >= 1) {
@@ -264,14 +266,14 @@ WideWs carve(void* base, long long N, int F, int Kp, int Cpad) {
 }
 
 int gemm(int epi, const float* A, const float* W, const float* bias, const float* g, const float* sh, const float* mul,
-         float* out, long long M, int K, int Nout, int ldo, hipStream_t stream) {
+         int mul_div, float* out, long long M, int K, int Nout, int ldo, hipStream_t stream) {
     dim3 grid((unsigned)(Nout / BN), (unsigned)((M + BM - 1) / BM));
     if (epi == EPI_SOFTPLUS)
-        wide_gemm_kernel<EPI_SOFTPLUS><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, out, M, K, ldo);
+        wide_gemm_kernel<EPI_SOFTPLUS><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo);
     else if (epi == EPI_SOFTPLUS_MUL)
-        wide_gemm_kernel<EPI_SOFTPLUS_MUL><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, out, M, K, ldo);
+        wide_gemm_kernel<EPI_SOFTPLUS_MUL><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo);
     else
-        wide_gemm_kernel<EPI_BIAS><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, out, M, K, ldo);
+        wide_gemm_kernel<EPI_BIAS><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo);
     HIP_TRY(hipGetLastError());
     return CARD_OK;
 }
@@ -344,13 +346,13 @@ int wide_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     auto forward = [&](int t) -> int {
         const float* g = s->gtab + (size_t)t * 3 * F;
         int rc;
-        if ((rc = gemm(EPI_SOFTPLUS_MUL, w.S, s->W1, b1, g, s->shift, r.x, w.hA, N, Kp, F, F, stream))) return rc;
-        if ((rc = gemm(EPI_SOFTPLUS, w.hA, s->W2, b2, g + F, s->shift + F, nullptr, w.hB, N, F, F, F, stream))) return rc;
-        if ((rc = gemm(EPI_SOFTPLUS, w.hB, s->W3, b3, g + 2 * (size_t)F, s->shift + 2 * (size_t)F, nullptr, w.hA, N, F, F, F, stream))) return rc;
-        return gemm(EPI_BIAS, w.hA, s->W4, b4, nullptr, nullptr, nullptr, w.eps, N, F, Cpad, Cpad, stream);
+        if ((rc = gemm(EPI_SOFTPLUS_MUL, w.S, s->W1, b1, g, s->shift, r.x, r.n_z, w.hA, N, Kp, F, F, stream))) return rc;
+        if ((rc = gemm(EPI_SOFTPLUS, w.hA, s->W2, b2, g + F, s->shift + F, nullptr, 1, w.hB, N, F, F, F, stream))) return rc;
+        if ((rc = gemm(EPI_SOFTPLUS, w.hB, s->W3, b3, g + 2 * (size_t)F, s->shift + 2 * (size_t)F, nullptr, 1, w.hA, N, F, F, F, stream))) return rc;
+        return gemm(EPI_BIAS, w.hA, s->W4, b4, nullptr, nullptr, nullptr, 1, w.eps, N, F, Cpad, Cpad, stream);
     };
     // static columns of S (+ y_t when the caller supplies it)
-    wide_pack_state_kernel<<<grid_for(N * Kp), 256, 0, stream>>>(r.y_init, r.y0hat, C, s->cat_y_pred, Kp, N, w.S);
+    wide_pack_state_kernel<<<grid_for(N * Kp), 256, 0, stream>>>(r.y_init, r.y0hat, C, s->cat_y_pred, Kp, r.n_z, N, w.S);
     HIP_TRY(hipGetLastError());
 
     if (r.eps_only) {
@@ -365,8 +367,8 @@ int wide_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     const int* sel = r.out_mode == CARD_OUT_SELECT ? r.state_slot : nullptr;
     auto fixed = [&](int state) -> long long { return r.out_mode == CARD_OUT_ALL ? state - base : -1; };
     if (!r.y_init) {
-        wide_init_kernel<<<grid_for(ne), 256, 0, stream>>>(r.ytmean, r.noise, r.seed, r.elem_offset, ne, C, Kp, w.S, r.out,
-                                                          sel, fixed(0));
+        wide_init_kernel<<<grid_for(ne), 256, 0, stream>>>(r.ytmean, r.noise, r.seed, r.elem_offset, ne, C, Kp, r.n_z, w.S,
+                                                          r.out, sel, fixed(0));
         HIP_TRY(hipGetLastError());
     }
     for (int t = r.t_hi; t >= r.t_lo; --t) {
@@ -374,7 +376,7 @@ int wide_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
         const int draw = T - t;
         const float* nz = (r.noise && t >= 1) ? r.noise + (long long)(draw - base) * ne : nullptr;
         wide_update_kernel<<<grid_for(ne), 256, 0, stream>>>(w.eps, Cpad, r.ytmean, r.coef + (size_t)t * CARD_COEF_COLS, nz,
-                                                            r.seed, r.elem_offset, draw, t, C, ne, Kp, w.S, r.out, sel, T - t,
+                                                            r.seed, r.elem_offset, draw, t, C, ne, Kp, r.n_z, w.S, r.out, sel, T - t,
                                                             fixed(T - t));
         HIP_TRY(hipGetLastError());
     }

@@ -124,18 +124,20 @@ def y_0_reparam(model, x, y, y_0_hat, y_T_mean, t, one_minus_alphas_bar_sqrt):
 
 
 def p_sample_loop(model, x, y_0_hat, y_T_mean, n_steps, alphas, one_minus_alphas_bar_sqrt, only_last_sample=False,
-                  *, noise=None, seed=None, elem_offset=0, states=None):
+                  *, noise=None, seed=None, elem_offset=0, states=None, n_z=1):
     """regression/diffusion_utils.py:107-119 (+ `only_last_sample`, classification/diffusion_utils.py:119-144).
 
     Returns the reference's list of n_steps+1 tensors (index k <-> timestep n_steps-k; views of one
     (n_steps+1, N, y_dim) buffer), or y_0 alone when only_last_sample.  `states=[...]` returns just those
     list positions (stacked), `noise=(n_steps, N, y_dim)` injects the reference's randn stream, otherwise
-    noise comes from the in-kernel Philox generator keyed by `seed` (default: drawn from torch's RNG)."""
+    noise comes from the in-kernel Philox generator keyed by `seed` (default: drawn from torch's RNG).
+    `n_z > 1`: x / y_0_hat / y_T_mean are the UN-tiled test rows and the kernel expands each to n_z chains
+    (what regression/card_regression.py:1027-1035 does with repeat/transpose/flatten before calling)."""
     s = sampler_for(model)
     T = int(n_steps)
     coef = coef_on_device(alphas, one_minus_alphas_bar_sqrt, T, s.device)
     seed = _fresh_seed() if (seed is None and noise is None) else int(seed or 0)
-    kw = dict(noise=noise, seed=seed, elem_offset=elem_offset)
+    kw = dict(noise=noise, seed=seed, elem_offset=elem_offset, n_z=n_z)
     x = _model_x(model, s, x)
     if states is not None:
         return s.run(x, y_0_hat, y_T_mean, coef, T, out_mode=_lib.OUT_SELECT, states=states, **kw)

@@ -32,6 +32,13 @@ def _default_sample_fn(model, x, y0, mu, n_steps, alphas, omabs, seed, elem_offs
     return p_sample_loop(model, x, y0, mu, n_steps, alphas, omabs, True, seed=seed, elem_offset=elem_offset)
 
 
+def _default_sample_rows_fn(model, x_rows, y0_rows, mu_rows, n_z, n_steps, alphas, omabs, seed, elem_offset):
+    """Un-tiled rows in, (rows * n_z, y_dim) out: the kernel does the (row, z) expansion (card_run_args.n_z)."""
+    from .diffusion_utils import p_sample_loop
+    return p_sample_loop(model, x_rows, y0_rows, mu_rows, n_steps, alphas, omabs, True, seed=seed,
+                         elem_offset=elem_offset, n_z=n_z)
+
+
 def sharded_sample_y0(model, x_rows, y_0_hat_rows, y_T_mean_rows, n_z: int, n_steps: int, alphas, omabs, *,
                       seed: int, group=None, gather: bool = True,
                       sample_fn: Optional[Callable] = None):
@@ -45,12 +52,15 @@ def sharded_sample_y0(model, x_rows, y_0_hat_rows, y_T_mean_rows, n_z: int, n_st
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     R, y_dim = y_0_hat_rows.shape
     lo, hi = row_shard(R, rank, world)
-    fn = sample_fn or _default_sample_fn
     if hi > lo:
-        x = tile_rows(x_rows[lo:hi], n_z)
-        y0 = tile_rows(y_0_hat_rows[lo:hi], n_z)
-        mu = tile_rows(y_T_mean_rows[lo:hi], n_z)
-        out = fn(model, x, y0, mu, n_steps, alphas, omabs, seed, lo * n_z * y_dim)
+        if sample_fn is None:        # GPU path: rows are expanded to chains inside the kernel
+            out = _default_sample_rows_fn(model, x_rows[lo:hi], y_0_hat_rows[lo:hi], y_T_mean_rows[lo:hi], n_z,
+                                          n_steps, alphas, omabs, seed, lo * n_z * y_dim)
+        else:
+            x = tile_rows(x_rows[lo:hi], n_z)
+            y0 = tile_rows(y_0_hat_rows[lo:hi], n_z)
+            mu = tile_rows(y_T_mean_rows[lo:hi], n_z)
+            out = sample_fn(model, x, y0, mu, n_steps, alphas, omabs, seed, lo * n_z * y_dim)
         local = out.reshape(hi - lo, n_z, y_dim)
     else:
         local = y_0_hat_rows.new_zeros((0, n_z, y_dim))

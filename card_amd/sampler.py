@@ -148,20 +148,24 @@ class Sampler:
         return t
 
     def run(self, x, y_0_hat, y_T_mean, coef, T, *, t_hi=None, t_lo=0, y_init=None, noise=None, seed=0,
-            elem_offset=0, out_mode=_lib.OUT_LAST, states=None):
-        """card_sampler_run.  Returns (N, y_dim) for OUT_LAST, (n_states, N, y_dim) otherwise."""
+            elem_offset=0, out_mode=_lib.OUT_LAST, states=None, n_z=1):
+        """card_sampler_run.  Returns (N, y_dim) for OUT_LAST, (n_states, N, y_dim) otherwise.
+        n_z > 1: x / y_0_hat / y_T_mean are per test ROW and every row is expanded to n_z chains inside the
+        kernel (N = rows * n_z, chain order (row, z) like regression/card_regression.py:1027-1035)."""
         T = int(T)
         t_hi = T - 1 if t_hi is None else int(t_hi)
         t_lo = int(t_lo)
         y0 = self._prep(y_0_hat, self.y_dim, "y_0_hat")
         mu = self._prep(y_T_mean, self.y_dim, "y_T_mean")
-        N = int(y0.shape[0])
+        n_z = max(1, int(n_z))
+        rows = int(y0.shape[0])
+        N = rows * n_z
         need_x = self.variant != _lib.VARIANT_GUIDED or (self.cat_x and self.x_dim > 0)
         xx = self._prep(x, self.x_dim, "x") if need_x else None
         yi = self._prep(y_init, self.y_dim, "y") if y_init is not None else None
-        for name, t in (("x", xx), ("y_T_mean", mu), ("y", yi)):
-            if t is not None and t.shape[0] != N:
-                raise CardError(f"{name} has {t.shape[0]} rows, y_0_hat has {N}")
+        for name, t, want in (("x", xx, rows), ("y_T_mean", mu, rows), ("y", yi, N)):
+            if t is not None and t.shape[0] != want:
+                raise CardError(f"{name} has {t.shape[0]} rows, expected {want}")
         n_steps = t_hi - t_lo + 1
         n_states = n_steps + (0 if yi is not None else 1)
         n_draws = (0 if yi is not None else 1) + (t_hi - max(t_lo, 1) + 1 if t_hi >= 1 else 0)
@@ -190,7 +194,7 @@ class Sampler:
         a.x, a.y_0_hat, a.y_T_mean, a.y_init = _ptr(xx), _ptr(y0), _ptr(mu), _ptr(yi)
         a.coef, a.noise = _ptr(coef), _ptr(nz)
         a.seed, a.elem_offset = int(seed) & (2 ** 64 - 1), int(elem_offset)
-        a.out, a.out_mode, a.state_slot = _ptr(out), out_mode, _ptr(slot)
+        a.out, a.out_mode, a.state_slot, a.n_z = _ptr(out), out_mode, _ptr(slot), n_z
         ws, a.workspace, a.workspace_bytes = self._workspace(N)
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().card_sampler_run(self._h, C.byref(a), _stream(self.device)), "card_sampler_run")

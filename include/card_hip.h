@@ -126,6 +126,10 @@ typedef struct card_run_args {
                                how rows are sharded over GPUs / calls */
     float* out;             /* device, see card_out_mode */
     int32_t out_mode;
+    int32_t n_z;            /* > 1: x, y_0_hat and y_T_mean hold N / n_z ROWS and chain i reads row i / n_z, i.e. the
+                               reference's repeat-tiling of each test row into n_z chains
+                               (regression/card_regression.py:1027-1035) happens inside the kernel.  0 or 1: they
+                               hold N rows.  y_init, noise and out are always per chain. */
     const int32_t* state_slot; /* device (T+1) ints, CARD_OUT_SELECT only */
     void* workspace;        /* device scratch, 256-byte aligned, card_sampler_workspace_bytes(s, N) bytes
                                (BN_HADAMARD: activations between the per-step GEMMs; GUIDED needs none: NULL) */

@@ -149,3 +149,16 @@ def test_cls_wide_widths_against_oracle(F, C):
     assert worst <= TOL
     eps = s.eps_theta(cuda(xf), cuda(want[2]), cuda(y0), 3).cpu()
     assert norm_rel_err(eps, orc.eps_theta(w, xf, want[2], y0, 3)) <= TOL
+
+
+def test_cls_in_kernel_row_tiling():
+    from card_amd.distributed import tile_rows
+    g = load_golden("cls_mnist_T50")
+    s = Sampler.from_cls_state_dict(g["sd"], device=DEV)
+    coef = cuda(make_coef_table(g["alphas"], g["omabs"]))
+    rows, n_z, T = 5, 40, g["T"]
+    xf, y0 = g["x_feat"][:rows], g["y0hat"][:rows]
+    a = s.run(cuda(xf), cuda(y0), cuda(y0), coef, T, seed=11, n_z=n_z, out_mode=_lib.OUT_ALL)
+    b = s.run(cuda(tile_rows(xf, n_z)), cuda(tile_rows(y0, n_z)), cuda(tile_rows(y0, n_z)), coef, T, seed=11,
+              out_mode=_lib.OUT_ALL)
+    assert a.shape == (T + 1, rows * n_z, y0.shape[1]) and torch.equal(a, b)

@@ -267,3 +267,26 @@ def test_end_to_end_rng_statistics_match_reference_sampling():
     lo, hi = np.percentile(ref.numpy(), [2.5, 97.5], axis=1)
     cover = ((hip.numpy() >= lo[:, None]) & (hip.numpy() <= hi[:, None])).mean()
     assert abs(cover - 0.95) < 0.01
+
+
+def test_in_kernel_row_tiling_equals_host_tiling():
+    """n_z > 1 (rows expanded to chains inside the kernel) == the reference's host-side repeat tiling
+    (regression/card_regression.py:1027-1035), bit for bit, in RNG and injected-noise mode."""
+    from card_amd.distributed import tile_rows
+    for name in ("reg_boston_T50", "reg_year_T50"):
+        g = load_golden(name)
+        s = Sampler.from_state_dict(g["sd"], device=DEV)
+        coef = cuda(make_coef_table(g["alphas"], g["omabs"]))
+        rows, n_z, T = 9, 37, g["T"]
+        x, y0 = g["x"][:rows], g["y0hat"][:rows]
+        a = s.run(cuda(x), cuda(y0), cuda(y0), coef, T, seed=3, n_z=n_z, out_mode=_lib.OUT_ALL)
+        b = s.run(cuda(tile_rows(x, n_z)), cuda(tile_rows(y0, n_z)), cuda(tile_rows(y0, n_z)), coef, T, seed=3,
+                  out_mode=_lib.OUT_ALL)
+        assert a.shape == (T + 1, rows * n_z, 1) and torch.equal(a, b)
+        z = torch.randn(T, rows * n_z, 1)
+        a = s.run(cuda(x), cuda(y0), cuda(y0), coef, T, noise=cuda(z), n_z=n_z)
+        want = orc.p_sample_loop(g["weights"], tile_rows(x, n_z), tile_rows(y0, n_z), tile_rows(y0, n_z), T, g["alphas"],
+                                 g["omabs"], z, only_last_sample=True)
+        assert norm_rel_err(a.cpu(), want) <= TOL
+    with pytest.raises(_lib.CardError):
+        s.run(cuda(x), cuda(y0), cuda(y0[:-1]), coef, T, n_z=n_z)
