@@ -13,6 +13,7 @@ COEF_COLS = 8
 EXPORTS = (
     "card_version", "card_last_error", "card_make_coef_table", "card_sampler_create", "card_sampler_destroy",
     "card_sampler_run", "card_sampler_workspace_bytes", "card_eps_theta", "card_q_sample", "card_philox_normal",
+    "card_regression_row_metrics",
 )
 
 _fp = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
@@ -33,6 +34,15 @@ class RunArgs(C.Structure):
         ("N", C.c_int64), ("x", _fp), ("y_0_hat", _fp), ("y_T_mean", _fp), ("y_init", _fp), ("coef", _fp),
         ("noise", _fp), ("seed", C.c_uint64), ("elem_offset", C.c_uint64), ("out", _fp),
         ("out_mode", C.c_int32), ("n_z", C.c_int32), ("state_slot", _fp), ("workspace", _fp), ("workspace_bytes", C.c_uint64),
+    ]
+
+
+class MetricArgs(C.Structure):
+    _fields_ = [
+        ("struct_bytes", C.c_int32), ("n_z", C.c_int32), ("rows", C.c_int64), ("n_states", C.c_int32),
+        ("n_bins", C.c_int32), ("samples", _fp), ("y_true", _fp), ("y_scale", C.c_float), ("y_shift", C.c_float),
+        ("trim_lo", C.c_float), ("trim_hi", C.c_float), ("picp_lo", C.c_float), ("picp_hi", C.c_float),
+        ("tau", C.c_float), ("se", _fp), ("nll", _fp), ("qice_bin", _fp), ("picp_in", _fp),
     ]
 
 
@@ -64,6 +74,7 @@ def lib():
     L.card_eps_theta.argtypes = [C.c_void_p, _fp, _fp, _fp, C.c_int64, C.c_int32, _fp, _fp, C.c_uint64, C.c_void_p]
     L.card_q_sample.argtypes = [_fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_uint64,
                                 C.c_uint64, _fp, C.c_void_p]
+    L.card_regression_row_metrics.argtypes = [C.POINTER(MetricArgs), C.c_void_p]
     L.card_philox_normal.argtypes = [C.c_uint64, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = a symbol the header declares is not exported

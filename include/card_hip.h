@@ -164,6 +164,30 @@ CARD_API int card_q_sample(const float* y, const float* y_0_hat, const float* al
 CARD_API int card_philox_normal(uint64_t seed, uint64_t elem_offset, int64_t n_elems, int32_t draw0, int32_t n_draws,
                        float* out, void* stream);
 
+/* Per-row evaluation statistics of generated samples (y_dim = 1), computed on the device.
+ * Replaces the numpy side of Diffusion.test: compute_prediction_SE (regression/card_regression.py:763-784),
+ * compute_true_coverage_by_gen_QI (:786-811, per-row decile membership), compute_PICP (:813-825) and
+ * compute_batch_NLL (:866-893).  Sums over rows (and the all-reduce over GPUs) are left to the caller. */
+typedef struct card_metric_args {
+    int32_t struct_bytes;
+    int32_t n_z;            /* samples per row, <= 8192 */
+    int64_t rows;
+    int32_t n_states;       /* leading dimension of samples: metrics for several trajectory states at once */
+    int32_t n_bins;         /* config.testing.n_bins (10) */
+    const float* samples;   /* device (n_states, rows, n_z): chain order (row, z) of the sampler output */
+    const float* y_true;    /* device (rows): normalised targets */
+    float y_scale, y_shift; /* un-normalise v -> v*scale + shift for SE and NLL (scaler_y.inverse_transform); 1, 0 if none */
+    float trim_lo, trim_hi; /* config.testing.trimmed_mean_range in percent (0, 100) */
+    float picp_lo, picp_hi; /* config.testing.PICP_range in percent (2.5, 97.5) */
+    float tau;              /* > 0: global precision (set_NLL_global_precision); <= 0: per-row 1/var of the samples */
+    float* se;              /* out (n_states, rows): squared error of the trimmed-mean prediction */
+    float* nll;             /* out (n_states, rows) */
+    int32_t* qice_bin;      /* out (n_states, rows): decile boundaries below y_true, 0 .. n_bins+1 */
+    int32_t* picp_in;       /* out (n_states, rows): 1 if y_true lies inside the PICP interval */
+} card_metric_args;
+
+CARD_API int card_regression_row_metrics(const card_metric_args* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,72 @@
+"""On-device regression metrics against a numpy restatement of the reference's helpers
+(regression/card_regression.py:763-825, :866-893)."""
+import numpy as np
+import pytest
+import torch
+from scipy.special import logsumexp
+
+from card_amd import metrics
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def reference_metrics(gen, y, n_bins, picp, trim, scale, shift, tau):
+    """gen: (rows, n_z, 1) float32 normalised samples, y: (rows, 1).  Mirrors the reference line by line."""
+    rows, n_z, _ = gen.shape
+    g = gen.copy()
+    g.sort(axis=1)
+    lo, hi = int(trim[0] / 100 * n_z), int(trim[1] / 100 * n_z)
+    pred = g[:, lo:hi].mean(axis=1)
+    y_un = (y.astype(np.float64) * scale + shift).astype(np.float32)
+    pred_un = (pred.astype(np.float64) * scale + shift).astype(np.float32)
+    se = (pred_un - y_un) ** 2
+    quant = np.percentile(gen.squeeze(-1), q=np.arange(n_bins + 1) * (100 / n_bins), axis=1)
+    member = ((y.T - quant) > 0).astype(int).sum(axis=0)
+    ci = np.percentile(gen.squeeze(-1), q=list(picp), axis=1)
+    inr = ((y.T >= ci[0]) & (y.T <= ci[1])).reshape(-1)
+    gen_un = (gen.reshape(rows * n_z, 1).astype(np.float64) * scale + shift).astype(np.float32).reshape(rows, n_z, 1)
+    gen_un = gen_un.swapaxes(0, 1)
+    if tau is None:
+        t = 1 / torch.from_numpy(gen_un).var(dim=0, unbiased=True).numpy()
+    else:
+        t = tau
+    nll = -(logsumexp(-0.5 * t * (y_un[None] - gen_un) ** 2., 0) - np.log(n_z) - 0.5 * np.log(2 * np.pi)
+            + 0.5 * np.log(t))
+    return se.reshape(-1), nll.reshape(-1), member, inr.astype(int)
+
+
+@pytest.mark.parametrize("n_z,tau,trim", [(1000, 0.37, (0.0, 100.0)), (100, None, (0.0, 100.0)), (257, 1.0, (10.0, 90.0)),
+                                          (2, None, (0.0, 100.0))])
+def test_row_metrics_match_reference_formulas(n_z, tau, trim):
+    rng = np.random.default_rng(n_z)
+    rows, n_bins, picp = 97, 10, (2.5, 97.5)
+    loc = rng.normal(size=(rows, 1, 1))
+    gen = (loc + rng.normal(size=(rows, n_z, 1)) * rng.uniform(0.2, 2.0, size=(rows, 1, 1))).astype(np.float32)
+    y = (loc[:, 0] + rng.normal(size=(rows, 1)) * 1.5).astype(np.float32)
+    scale, shift = 9.2, 22.5
+    se, nll, member, inr = reference_metrics(gen, y, n_bins, picp, trim, scale, shift, tau)
+    m = metrics.regression_row_metrics(torch.from_numpy(gen).to(DEV), torch.from_numpy(y).to(DEV), n_bins=n_bins,
+                                       picp_range=picp, trimmed_mean_range=trim, y_scale=scale, y_shift=shift, tau=tau)
+    assert np.array_equal(m["qice_bin"][0].cpu().numpy(), member)
+    assert np.array_equal(m["picp_in"][0].cpu().numpy(), inr)
+    np.testing.assert_allclose(m["se"][0].cpu().numpy(), se, rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(m["nll"][0].cpu().numpy(), nll, rtol=2e-4, atol=2e-4)
+
+
+def test_metric_sums_over_states_and_finalize():
+    rng = np.random.default_rng(5)
+    n_states, rows, n_z, n_bins = 3, 60, 500, 10
+    gen = rng.normal(size=(n_states, rows, n_z, 1)).astype(np.float32)
+    y = rng.normal(size=(rows, 1)).astype(np.float32)
+    sums = metrics.regression_metric_sums(torch.from_numpy(gen).to(DEV), torch.from_numpy(y).to(DEV), n_bins=n_bins, tau=1.0)
+    fin = metrics.finalize(sums, n_bins)
+    for k in range(n_states):
+        se, nll, member, inr = reference_metrics(gen[k], y, n_bins, (2.5, 97.5), (0.0, 100.0), 1.0, 0.0, 1.0)
+        counts = np.array([(member == v).sum() for v in np.arange(n_bins + 2)])
+        counts[1] += counts[0]; counts[-2] += counts[-1]
+        qice = np.absolute(np.ones(n_bins) / n_bins - counts[1:-1] / rows).mean()
+        assert abs(float(fin["rmse"][k]) - np.sqrt(se.mean())) < 1e-4
+        assert abs(float(fin["picp"][k]) - inr.mean()) < 1e-12
+        assert abs(float(fin["qice"][k]) - qice) < 1e-12
+        assert abs(float(fin["nll"][k]) - nll.mean()) < 1e-4
