@@ -28,6 +28,16 @@ PEAK_FP32_MATRIX_TFLOPS = 157.3       # MI355X_MICROARCH.md, "Peak FP32 (matrix)
 TILE_M, WAVES_PER_CU, TILES_PER_WAVE_PER_LAUNCH = 32, 8, 16   # launch_sampler() in card_amd/csrc/card_hip.hip
 
 
+# shape presets: name -> (rows per GPU, n_z, x_dim, description)
+WORKLOADS = {
+    "toy": (10_000, 1000, 1, "toy 8-Gaussians shape (BASELINE configs[1]: 10k test x, 1000 z-samples, toy_8gauss.yml)"),
+    "boston": (51, 100, 13, "UCI Boston plumbing shape (BASELINE configs[0]: 51 test rows x 100 z-samples, x_dim=13)"),
+    "year": (64_418, 200, 90, "UCI YearPredictionMSD shape, one GPU's 1/8 shard (BASELINE configs[2]: 515 345 rows / 8, "
+                              "200 z-samples, 90 features)"),
+    "sweep": (1_000_000, 100, 13, "synthetic 1M rows x 100 z-samples, x_dim=13, H=128 (BASELINE configs[4])"),
+}
+
+
 def synth_state_dict(x_dim, T, seed=1234):
     """Random-init weights of regression/model.py:21 ConditionalGuidedModel (nn.Linear default init, gamma
     tables U(0,1) as regression/model.py:12, lin4 scaled x0.1 per SURVEY.md section 8d)."""
@@ -73,9 +83,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--rows", type=int, default=10_000, help="test rows per GPU")
-    ap.add_argument("--nz", type=int, default=1000, help="z-samples per row")
-    ap.add_argument("--x-dim", type=int, default=1)
+    ap.add_argument("--workload", default="toy", choices=sorted(WORKLOADS),
+                    help="shape preset (BASELINE.json configs); toy = configs[1], the headline line")
+    ap.add_argument("--rows", type=int, default=None, help="test rows per GPU (default: preset)")
+    ap.add_argument("--nz", type=int, default=None, help="z-samples per row (default: preset)")
+    ap.add_argument("--x-dim", type=int, default=None)
     ap.add_argument("--T", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
@@ -102,6 +114,10 @@ def main():
     from card_amd.sampler import Sampler, make_coef_table
     from oracle.card_oracle import make_schedule   # schedule constructor only (host-side setup, not measured)
 
+    preset = WORKLOADS[a.workload]
+    a.rows = preset[0] if a.rows is None else a.rows
+    a.nz = preset[1] if a.nz is None else a.nz
+    a.x_dim = preset[2] if a.x_dim is None else a.x_dim
     T, x_dim = a.T, a.x_dim
     N = a.rows * a.nz
     d_in = x_dim + 2
@@ -111,18 +127,18 @@ def main():
     sampler = Sampler.from_state_dict(sd, device=dev)
     coef = make_coef_table(alphas, omabs).to(dev)
 
-    # synthetic inputs, tiled (row, z) like regression/card_regression.py:1027-1035, resident in HBM
+    # synthetic test rows resident in HBM; the (row, z) tiling of regression/card_regression.py:1027-1035 is done
+    # inside the kernel (card_run_args.n_z)
     g = torch.Generator().manual_seed(1234 + rank)
     x_rows = torch.randn(a.rows, x_dim, generator=g)
     y0_rows = torch.randn(a.rows, 1, generator=g)
-    x = x_rows.to(dev).repeat_interleave(a.nz, 0).contiguous()
-    y0 = y0_rows.to(dev).repeat_interleave(a.nz, 0).contiguous()
+    x, y0 = x_rows.to(dev), y0_rows.to(dev)
     elem_offset = rank * N
     y_true = (y0_rows + 0.3 * torch.randn(a.rows, 1, generator=g)).to(dev)
     from card_amd.distributed import regression_metric_sums, all_reduce_sums
 
     def one_step(i):
-        y = sampler.run(x, y0, y0, coef, T, seed=1234 + i, elem_offset=elem_offset, out_mode=_lib.OUT_LAST)
+        y = sampler.run(x, y0, y0, coef, T, seed=1234 + i, elem_offset=elem_offset, out_mode=_lib.OUT_LAST, n_z=a.nz)
         if use_dist:
             # evaluation sums (n, squared error, PICP count, QICE bin counts: card_regression.py:776-821) of this
             # rank's rows, then ONE 15-element RCCL all-reduce per loop -- the only collective on the path
@@ -179,9 +195,9 @@ def main():
             "value": value, "unit": "sample-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"toy 8-Gaussians shape (BASELINE configs[1]): {a.rows} test rows x {a.nz} "
-                                   f"z-samples per GPU, x_dim={x_dim} (d_in={d_in}), H={H}, T={T}, "
-                                   "in-kernel Philox noise, last-sample output, random-init weights",
+            "config": {"workload": f"{preset[3]}: {a.rows} test rows x {a.nz} z-samples per GPU, x_dim={x_dim} "
+                                   f"(d_in={d_in}), H={H}, T={T}, in-kernel Philox noise, last-sample output, "
+                                   "random-init weights",
                        "rows_per_gpu": a.rows, "n_z": a.nz, "T": T, "sharding": f"rows x{world}, no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
@@ -191,10 +207,12 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             threads = torch.get_num_threads()
             rows_cpu, steps_cpu = 256 * 1000, 40      # one reference minibatch of toy_8gauss.yml (:67, :72)
+            if a.workload != "toy":
+                rows_cpu = min(N, 64 * a.nz)          # one reference minibatch: testing.batch_size 64 x n_z
             v, dt = cpu_baseline(sd, x_dim, T, rows_cpu, steps_cpu, alphas, omabs)
             out["cpu_baseline"] = {"value": v, "unit": "sample-steps/s", "cores": threads, "kind": "port",
                                    "sample": f"{steps_cpu} of the {T} timesteps of one reference minibatch "
-                                             f"(256 rows x 1000 z = {rows_cpu} chains), torch CPU fp32, {dt:.1f} s"}
+                                             f"({rows_cpu} chains), torch CPU fp32, {dt:.1f} s"}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:

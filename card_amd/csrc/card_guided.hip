@@ -117,13 +117,14 @@ __device__ __forceinline__ void layer_hidden(const float* wl, const float* bl, c
 // Layer 1 with the step-invariant part hoisted: the accumulator starts from this wave's scratch slot
 // c1 = b1 + W1[:, 1:] . (y_0_hat, x) (computed once per tile) and one K=2 MFMA per output tile adds
 // W1[:, 0] * y_t (a10: column 0 on lanes 0-31, zero on lanes 32-63; yb: y_t on lanes 0-31, zero above).
+template <int STRIDE>   // floats between consecutive (j, q) fragments: 256 in a global slot, 8 in an LDS row
 __device__ __forceinline__ void layer_first_hoisted(const float* slot, const float (&a10)[4], float yb,
                                                     const float* gl, f32x16 (&hout)[4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 c = *reinterpret_cast<const f32x4*>(slot + (j * 4 + q) * 256);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(slot + (j * 4 + q) * STRIDE);
             hout[j][4 * q + 0] = c[0]; hout[j][4 * q + 1] = c[1]; hout[j][4 * q + 2] = c[2]; hout[j][4 * q + 3] = c[3];
         }
     }
@@ -156,11 +157,14 @@ __device__ __forceinline__ void layer_first(const float* wl, const float* bl, co
 
 // ------------------------------------------------------------------------------------------------
 // The persistent sampler kernel (CARD_VARIANT_GUIDED, y_dim = 1, H = 128).
-//   HOIST = false: layer 1 runs on MFMA every step with W1 (K padded to K1 <= 32) resident in LDS.
-//   HOIST = true : any d_in; the step-invariant part of layer 1 is computed once per tile into the wave's
+//   HOIST = 0    : layer 1 runs on MFMA every step with W1 (K padded to K1 <= 32) resident in LDS.
+//   HOIST = 1    : any d_in; the step-invariant part of layer 1 is computed once per tile into the wave's
 //                  scratch slot (16 KB, re-read from L2 every step) and only W1[:,0]*y_t is added per step.
 // ------------------------------------------------------------------------------------------------
-template <int K1, bool HOIST>
+//   HOIST = 2    : as 1, for in-kernel row tiling with n_z >= 32: the 32 chains of a tile then come from at most
+//                  two test rows, so the hoisted tile has only two distinct columns and lives in 1 KB of LDS per
+//                  wave -- no scratch slots, no per-step global traffic at all.
+template <int K1, int HOIST>
 __global__ __launch_bounds__(kThreads, 2) void card_sample_guided_kernel(const RunParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int IMG = img_floats(HOIST ? 1 : K1);
@@ -182,10 +186,11 @@ __global__ __launch_bounds__(kThreads, 2) void card_sample_guided_kernel(const R
     const float b4 = lds[kOffB4];
     float a10[4] = {0.f, 0.f, 0.f, 0.f};
     float* slot = nullptr;
-    if constexpr (HOIST) {
+    float* crow = lds + IMG + kWaves * kGammaRow + wave * (2 * kH) + 4 * hh;   // HOIST == 2: two hoisted columns
+    if constexpr (HOIST != 0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) a10[j] = hh == 0 ? lds[kOffW1 + 32 * j + m] : 0.0f;
-        slot = p.ws + ((long long)blockIdx.x * kWaves + wave) * kSlotFloats + lane * 4;
+        if constexpr (HOIST == 1) slot = p.ws + ((long long)blockIdx.x * kWaves + wave) * kSlotFloats + lane * 4;
     }
 
     const long long n_rows = p.n_end - p.n_begin;
@@ -213,7 +218,8 @@ __global__ __launch_bounds__(kThreads, 2) void card_sample_guided_kernel(const R
         // layer-1 input in B-operand order: k-step r takes feature 2r (lanes 0-31) and 2r+1 (lanes 32-63);
         // feature 0 (y_t) is rewritten every step.
         float h0[K1 / 2];
-        if constexpr (!HOIST) {
+        int sel = 0;                       // HOIST == 2: which of the tile's two test rows this chain belongs to
+        if constexpr (HOIST == 0) {
 #pragma unroll
             for (int r = 0; r < K1 / 2; ++r) {
                 const int k = 2 * r + hh;
@@ -235,17 +241,38 @@ __global__ __launch_bounds__(kThreads, 2) void card_sample_guided_kernel(const R
                     for (int e = 0; e < 4; ++e) c[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bq[e], c[j], 0, 0, 0);
                 }
             }
+            if constexpr (HOIST == 1) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 4; ++j) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 v = {c[j][4 * q + 0], c[j][4 * q + 1], c[j][4 * q + 2], c[j][4 * q + 3]};
-                    *reinterpret_cast<f32x4*>(slot + (j * 4 + q) * 256) = v;
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v = {c[j][4 * q + 0], c[j][4 * q + 1], c[j][4 * q + 2], c[j][4 * q + 3]};
+                        *reinterpret_cast<f32x4*>(slot + (j * 4 + q) * 256) = v;
+                    }
                 }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                // n_z >= 32: chains of this tile come from test row rowA or rowA + 1; the first chain of each row
+                // publishes its column of c (its 64 features per lane half) to the wave's LDS rows
+                const long long rowA = (p.n_begin + tile * kTileM) / p.n_z;
+                sel = rr != rowA ? 1 : 0;
+                const unsigned long long second = __ballot(sel == 1) & 0xFFFFFFFFull;
+                const int first_b = second ? __builtin_ctzll(second) : -1;
+                __builtin_amdgcn_wave_barrier();
+                if (m == 0 || m == first_b) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4 v = {c[j][4 * q + 0], c[j][4 * q + 1], c[j][4 * q + 2], c[j][4 * q + 3]};
+                            *reinterpret_cast<f32x4*>(crow + sel * kH + 32 * j + 8 * q) = v;
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        const float s0 = HOIST ? 0.0f : h0[0];
+        const float s0 = HOIST != 0 ? 0.0f : h0[0];
 
         float zc[4];
         uint32_t zblock = 0xFFFFFFFFu;
@@ -290,10 +317,14 @@ __global__ __launch_bounds__(kThreads, 2) void card_sample_guided_kernel(const R
             const float z = t >= 1 && !p.eps_only ? draw(T - t) : 0.0f;
 
             f32x16 hA[4], hB[4];
-            if constexpr (HOIST) {
+            if constexpr (HOIST == 1) {
                 const float* sp = slot;
                 asm volatile("" : "+v"(sp));      // keep the slot reads inside the step loop (no LICM into 64 VGPRs)
-                layer_first_hoisted(sp, a10, hh == 0 ? y : 0.0f, gl, hA);
+                layer_first_hoisted<256>(sp, a10, hh == 0 ? y : 0.0f, gl, hA);
+            } else if constexpr (HOIST == 2) {
+                const float* sp = crow + sel * kH;
+                asm volatile("" : "+v"(sp));
+                layer_first_hoisted<8>(sp, a10, hh == 0 ? y : 0.0f, gl, hA);
             } else {
                 h0[0] = hh == 0 ? y : s0;
                 layer_first<K1>(w1l, bl, gl, h0, hA);
@@ -399,13 +430,14 @@ __global__ void pack_gamma_kernel(const float* g1, const float* g2, const float*
 
 typedef void (*sample_kernel_t)(const RunParams);
 
-sample_kernel_t guided_kernel_for(int k1, bool hoist) {
-    if (hoist) return card_sample_guided_kernel<8, true>;
+sample_kernel_t guided_kernel_for(int k1, int hoist) {
+    if (hoist == 1) return card_sample_guided_kernel<8, 1>;
+    if (hoist == 2) return card_sample_guided_kernel<8, 2>;
     switch (k1) {
-        case 8: return card_sample_guided_kernel<8, false>;
-        case 16: return card_sample_guided_kernel<16, false>;
-        case 24: return card_sample_guided_kernel<24, false>;
-        case 32: return card_sample_guided_kernel<32, false>;
+        case 8: return card_sample_guided_kernel<8, 0>;
+        case 16: return card_sample_guided_kernel<16, 0>;
+        case 24: return card_sample_guided_kernel<24, 0>;
+        case 32: return card_sample_guided_kernel<32, 0>;
         default: return nullptr;
     }
 }
@@ -422,16 +454,17 @@ int guided_create(card_sampler* s, const card_model_desc* d, hipStream_t stream)
     if (const char* ev = getenv("CARD_AMD_HOIST")) hoist = d_in > 32 || ev[0] != '0';
     const int k1 = hoist ? 1 : (d_in + 7) / 8 * 8;
     const int nqs = (d_in - 1 + 7) / 8;
-    sample_kernel_t kern = guided_kernel_for(k1, hoist);
+    sample_kernel_t kern = guided_kernel_for(k1, hoist ? 1 : 0);
     if (!kern) return card_fail(CARD_E_UNSUPPORTED, "card_sampler_create: no kernel for d_in=%d", d_in);
     s->k1 = k1; s->kernel = kern; s->hoist = hoist ? 1 : 0; s->nqs = nqs;
     const int img = img_floats(k1);
-    s->lds_bytes = (size_t)(img + kWaves * kGammaRow) * sizeof(float);
+    s->lds_bytes = (size_t)(img + kWaves * kGammaRow + (hoist ? kWaves * 2 * kH : 0)) * sizeof(float);
     HIP_TRY(hipMalloc(&s->wpk, (size_t)img * sizeof(float)));
     HIP_TRY(hipMalloc(&s->gtab, (size_t)d->n_embed * kGammaRow * sizeof(float)));
     if (hoist && nqs > 0) HIP_TRY(hipMalloc(&s->w1s, (size_t)kH * 8 * nqs * sizeof(float)));
     if (hoist) HIP_TRY(hipMalloc(&s->ws, (size_t)s->num_cu * kWaves * kSlotFloats * sizeof(float)));
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
+    if (hoist) HIP_TRY(hipFuncSetAttribute((const void*)guided_kernel_for(k1, 2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
     pack_hidden_kernel<<<kH * kH / 256, 256, 0, stream>>>(d->W[1], kLn2, s->wpk + kOffW2);
     pack_hidden_kernel<<<kH * kH / 256, 256, 0, stream>>>(d->W[2], kLn2, s->wpk + kOffW3);
     if (hoist) {
@@ -475,7 +508,9 @@ int guided_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
         const long long tiles = (p.n_end - p.n_begin + kTileM - 1) / kTileM;
         long long grid = (tiles + kWaves - 1) / kWaves;
         if (grid > s->num_cu) grid = s->num_cu;
-        s->kernel<<<dim3((unsigned)grid), dim3(kThreads), s->lds_bytes, stream>>>(p);
+        // in-kernel row tiling with n_z >= 32: the hoisted layer-1 tile has two distinct columns -> LDS-resident form
+        sample_kernel_t kern = (s->hoist && r.n_z >= 32) ? guided_kernel_for(s->k1, 2) : s->kernel;
+        kern<<<dim3((unsigned)grid), dim3(kThreads), s->lds_bytes, stream>>>(p);
         HIP_TRY(hipGetLastError());
     }
     return CARD_OK;

@@ -277,12 +277,15 @@ def test_in_kernel_row_tiling_equals_host_tiling():
         g = load_golden(name)
         s = Sampler.from_state_dict(g["sd"], device=DEV)
         coef = cuda(make_coef_table(g["alphas"], g["omabs"]))
-        rows, n_z, T = 9, 37, g["T"]
+        rows, T = 9, g["T"]
         x, y0 = g["x"][:rows], g["y0hat"][:rows]
-        a = s.run(cuda(x), cuda(y0), cuda(y0), coef, T, seed=3, n_z=n_z, out_mode=_lib.OUT_ALL)
-        b = s.run(cuda(tile_rows(x, n_z)), cuda(tile_rows(y0, n_z)), cuda(tile_rows(y0, n_z)), coef, T, seed=3,
-                  out_mode=_lib.OUT_ALL)
-        assert a.shape == (T + 1, rows * n_z, 1) and torch.equal(a, b)
+        # n_z >= 32 takes the LDS-resident two-column form of the hoisted layer 1, n_z < 32 the scratch-slot form
+        for n_z in (5, 32, 37, 1000):
+            a = s.run(cuda(x), cuda(y0), cuda(y0), coef, T, seed=3, n_z=n_z, out_mode=_lib.OUT_ALL)
+            b = s.run(cuda(tile_rows(x, n_z)), cuda(tile_rows(y0, n_z)), cuda(tile_rows(y0, n_z)), coef, T, seed=3,
+                      out_mode=_lib.OUT_ALL)
+            assert a.shape == (T + 1, rows * n_z, 1) and torch.equal(a, b), n_z
+        n_z = 37
         z = torch.randn(T, rows * n_z, 1)
         a = s.run(cuda(x), cuda(y0), cuda(y0), coef, T, noise=cuda(z), n_z=n_z)
         want = orc.p_sample_loop(g["weights"], tile_rows(x, n_z), tile_rows(y0, n_z), tile_rows(y0, n_z), T, g["alphas"],
