@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CARD_AMD_LIB") or os.path.join(_HERE, "libcard_hip.so")  # override: kernel A/B builds
 
 CARD_OK = 0
-VARIANT_GUIDED, VARIANT_BN_HADAMARD = 0, 1
+VARIANT_GUIDED, VARIANT_BN_HADAMARD, VARIANT_LINEAR_HADAMARD = 0, 1, 2
 OUT_LAST, OUT_ALL, OUT_SELECT = 0, 1, 2
 COEF_COLS = 8
 

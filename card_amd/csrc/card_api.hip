@@ -94,10 +94,10 @@ extern "C" CARD_API int card_sampler_create(const card_model_desc* d, void* stre
     *out = nullptr;
     if (d->struct_bytes != (int32_t)sizeof(card_model_desc))
         return fail(CARD_E_INVALID, "card_sampler_create: struct_bytes %d != %zu", d->struct_bytes, sizeof(card_model_desc));
-    if (d->variant != CARD_VARIANT_GUIDED && d->variant != CARD_VARIANT_BN_HADAMARD)
+    if (d->variant < CARD_VARIANT_GUIDED || d->variant > CARD_VARIANT_LINEAR_HADAMARD)
         return fail(CARD_E_INVALID, "card_sampler_create: unknown variant %d", d->variant);
     if (d->n_embed < 1 || d->x_dim < 0 || d->y_dim < 1 || d->hidden < 1) return fail(CARD_E_INVALID, "card_sampler_create: bad n_embed/x_dim/y_dim/hidden");
-    for (int l = 0; l < 3; ++l)
+    for (int l = 0; l < (d->variant == CARD_VARIANT_LINEAR_HADAMARD ? 2 : 3); ++l)
         if (!d->W[l] || !d->b[l] || !d->gamma[l]) return fail(CARD_E_INVALID, "card_sampler_create: null weight pointer (layer %d)", l + 1);
     if (!d->W4 || !d->b4) return fail(CARD_E_INVALID, "card_sampler_create: null lin4 pointer");
     card_sampler* s = new (std::nothrow) card_sampler();
@@ -107,7 +107,7 @@ extern "C" CARD_API int card_sampler_create(const card_model_desc* d, void* stre
     s->n_embed = d->n_embed; s->cat_x = d->cat_x ? 1 : 0; s->cat_y_pred = d->cat_y_pred ? 1 : 0;
     s->d_in = d->variant == CARD_VARIANT_GUIDED
                   ? d->y_dim + (d->cat_y_pred ? d->y_dim : 0) + (d->cat_x ? d->x_dim : 0)
-                  : d->y_dim * (d->cat_y_pred ? 2 : 1);
+                  : d->y_dim * (d->cat_y_pred ? 2 : 1);   /* cat(y_t, y_0_hat) when `guidance` */
     hipError_t e;
     if ((e = hipGetDevice(&s->device)) != hipSuccess ||
         (e = hipDeviceGetAttribute(&s->num_cu, hipDeviceAttributeMultiprocessorCount, s->device)) != hipSuccess) {
@@ -133,7 +133,7 @@ extern "C" CARD_API void card_sampler_destroy(card_sampler* s) {
 
 extern "C" CARD_API int card_sampler_workspace_bytes(const card_sampler* s, int64_t N, uint64_t* bytes) {
     if (!s || !bytes || N < 0) return fail(CARD_E_INVALID, "card_sampler_workspace_bytes: bad argument");
-    *bytes = s->variant == CARD_VARIANT_BN_HADAMARD ? wide_workspace_bytes(s, N) : 0;
+    *bytes = s->variant != CARD_VARIANT_GUIDED ? wide_workspace_bytes(s, N) : 0;
     return CARD_OK;
 }
 
@@ -152,7 +152,7 @@ extern "C" CARD_API int card_sampler_run(const card_sampler* s, const card_run_a
     if (a->N == 0) return CARD_OK;  // empty batch: nothing to read or write
     if (!a->y_0_hat || !a->y_T_mean || !a->coef || !a->out)
         return fail(CARD_E_INVALID, "card_sampler_run: null y_0_hat / y_T_mean / coef / out");
-    const bool need_x = s->variant == CARD_VARIANT_BN_HADAMARD || (s->cat_x && s->x_dim > 0);
+    const bool need_x = s->variant != CARD_VARIANT_GUIDED || (s->cat_x && s->x_dim > 0);
     if (need_x && !a->x) return fail(CARD_E_INVALID, "card_sampler_run: x is NULL but the model reads x");
     if (a->out_mode == CARD_OUT_SELECT && !a->state_slot) return fail(CARD_E_INVALID, "card_sampler_run: CARD_OUT_SELECT needs state_slot");
     if (a->n_z < 0 || (a->n_z > 1 && a->N % a->n_z != 0))
@@ -172,7 +172,7 @@ extern "C" CARD_API int card_eps_theta(const card_sampler* s, const float* x, co
                                        int64_t N, int32_t t, float* out, void* workspace, uint64_t workspace_bytes,
                                        void* stream) {
     if (!s || !y_t || !y_0_hat || !out) return fail(CARD_E_INVALID, "card_eps_theta: null argument");
-    const bool need_x = s->variant == CARD_VARIANT_BN_HADAMARD || (s->cat_x && s->x_dim > 0);
+    const bool need_x = s->variant != CARD_VARIANT_GUIDED || (s->cat_x && s->x_dim > 0);
     if (need_x && !x) return fail(CARD_E_INVALID, "card_eps_theta: x is NULL but the model reads x");
     if (t < 0 || t >= s->n_embed) return fail(CARD_E_INVALID, "card_eps_theta: t=%d outside the gamma table", t);
     if (N < 0) return fail(CARD_E_INVALID, "card_eps_theta: N < 0");

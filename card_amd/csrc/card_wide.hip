@@ -28,7 +28,7 @@ constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 4;
 constexpr int kStageFloats = (BM + BN) * LDT;
 constexpr int kGemmLds = 2 * kStageFloats * (int)sizeof(float);   // 73 728 B -> two blocks per CU
 
-enum { EPI_SOFTPLUS = 0, EPI_BIAS = 1, EPI_SOFTPLUS_MUL = 2 };
+enum { EPI_SOFTPLUS = 0, EPI_BIAS = 1, EPI_SOFTPLUS_MUL = 2, EPI_SCALE = 3, EPI_SCALE_MUL = 4 };
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void wide_gemm_kernel(const float* __restrict__ A, const float* __restrict__ W,
@@ -116,9 +116,10 @@ __global__ __launch_bounds__(256, 2) void wide_gemm_kernel(const float* __restri
             for (int r = 0; r < 16; ++r) {
                 const long long row = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                 float v = acc[a][b][r] + bb;
-                if (EPI != EPI_BIAS) v = kLn2 * softplus_l2(fmaf(v, gg, ss));
+                if (EPI == EPI_SOFTPLUS || EPI == EPI_SOFTPLUS_MUL) v = kLn2 * softplus_l2(fmaf(v, gg, ss));
+                if (EPI == EPI_SCALE || EPI == EPI_SCALE_MUL) v = gg * v;      // gamma[t] * lin(x), builder.py:63-65
                 if (row < M) {
-                    if (EPI == EPI_SOFTPLUS_MUL) v *= mul[(row / mul_div) * ldo + col];   // Hadamard with x_feat (model.py:87)
+                    if (EPI == EPI_SOFTPLUS_MUL || EPI == EPI_SCALE_MUL) v *= mul[(row / mul_div) * ldo + col];   // Hadamard with x_feat (model.py:87)
                     out[row * ldo + col] = v;
                 }
             }
@@ -214,7 +215,8 @@ __global__ void wide_copy_eps_kernel(const float* __restrict__ eps, int ld_eps, 
 
 // create-time: gtab[t][l][f] = gamma_l[t][f] * bn_scale_l[f] * log2e ; shift'[l][f] = bn_shift_l[f] * log2e
 __global__ void wide_pack_gamma_kernel(const float* g1, const float* g2, const float* g3, const float* s1,
-                                       const float* s2, const float* s3, int n_embed, int F, float* __restrict__ gtab) {
+                                       const float* s2, const float* s3, float factor, int n_embed, int F,
+                                       float* __restrict__ gtab) {
     const long long total = (long long)n_embed * 3 * F;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
@@ -222,7 +224,7 @@ __global__ void wide_pack_gamma_kernel(const float* g1, const float* g2, const f
         const long long t = idx / (3LL * F);
         const float* g = l == 0 ? g1 : (l == 1 ? g2 : g3);
         const float* s = l == 0 ? s1 : (l == 1 ? s2 : s3);
-        gtab[idx] = (g[t * F + f] * s[f]) * kLog2e;
+        gtab[idx] = g ? (s ? g[t * F + f] * s[f] : g[t * F + f]) * factor : 0.0f;
     }
 }
 
@@ -272,6 +274,10 @@ int gemm(int epi, const float* A, const float* W, const float* bias, const float
         wide_gemm_kernel<EPI_SOFTPLUS><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo);
     else if (epi == EPI_SOFTPLUS_MUL)
         wide_gemm_kernel<EPI_SOFTPLUS_MUL><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo);
+    else if (epi == EPI_SCALE)
+        wide_gemm_kernel<EPI_SCALE><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo);
+    else if (epi == EPI_SCALE_MUL)
+        wide_gemm_kernel<EPI_SCALE_MUL><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo);
     else
         wide_gemm_kernel<EPI_BIAS><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo);
     HIP_TRY(hipGetLastError());
@@ -289,14 +295,15 @@ int wide_create(card_sampler* s, const card_model_desc* d, hipStream_t stream) {
     const int F = d->hidden, C = d->y_dim;
     if (F < 128 || F % 128) return card_fail(CARD_E_UNSUPPORTED, "card_sampler_create: BN_HADAMARD hidden=%d must be a multiple of 128", F);
     if (d->x_dim != F) return card_fail(CARD_E_INVALID, "card_sampler_create: BN_HADAMARD x_dim (%d) must equal hidden (%d): x is x_feat", d->x_dim, F);
-    for (int l = 0; l < 3; ++l)
+    const bool linear = d->variant == CARD_VARIANT_LINEAR_HADAMARD;   // imagenet/card/builder.py:69-92
+    for (int l = 0; l < 3 && !linear; ++l)
         if (!d->bn_scale[l] || !d->bn_shift[l]) return card_fail(CARD_E_INVALID, "card_sampler_create: BN_HADAMARD needs bn_scale/bn_shift (layer %d)", l + 1);
     const int d1 = s->d_in, Cpad = (C + BN - 1) / BN * BN;
     const size_t FF = (size_t)F * F;
     const int Kp = state_ld(s);
     HIP_TRY(hipMalloc(&s->W1, (size_t)F * Kp * 4));
     HIP_TRY(hipMalloc(&s->W2, FF * 4));
-    HIP_TRY(hipMalloc(&s->W3, FF * 4));
+    if (!linear) HIP_TRY(hipMalloc(&s->W3, FF * 4));
     HIP_TRY(hipMalloc(&s->W4, (size_t)Cpad * F * 4));
     HIP_TRY(hipMalloc(&s->bias, (size_t)(3 * F + Cpad) * 4));
     HIP_TRY(hipMalloc(&s->shift, (size_t)3 * F * 4));
@@ -304,19 +311,24 @@ int wide_create(card_sampler* s, const card_model_desc* d, hipStream_t stream) {
     HIP_TRY(hipFuncSetAttribute((const void*)wide_gemm_kernel<EPI_SOFTPLUS>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
     HIP_TRY(hipFuncSetAttribute((const void*)wide_gemm_kernel<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
     HIP_TRY(hipFuncSetAttribute((const void*)wide_gemm_kernel<EPI_SOFTPLUS_MUL>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
+    HIP_TRY(hipFuncSetAttribute((const void*)wide_gemm_kernel<EPI_SCALE>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
+    HIP_TRY(hipFuncSetAttribute((const void*)wide_gemm_kernel<EPI_SCALE_MUL>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
     wide_pad_cols_kernel<<<grid_for((long long)F * Kp), 256, 0, stream>>>(d->W[0], F, d1, Kp, s->W1);
     HIP_TRY(hipMemcpyAsync(s->W2, d->W[1], FF * 4, hipMemcpyDeviceToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(s->W3, d->W[2], FF * 4, hipMemcpyDeviceToDevice, stream));
+    if (!linear) HIP_TRY(hipMemcpyAsync(s->W3, d->W[2], FF * 4, hipMemcpyDeviceToDevice, stream));
     HIP_TRY(hipMemsetAsync(s->W4, 0, (size_t)Cpad * F * 4, stream));
     HIP_TRY(hipMemcpyAsync(s->W4, d->W4, (size_t)C * F * 4, hipMemcpyDeviceToDevice, stream));
     HIP_TRY(hipMemsetAsync(s->bias, 0, (size_t)(3 * F + Cpad) * 4, stream));
-    for (int l = 0; l < 3; ++l) {
+    HIP_TRY(hipMemsetAsync(s->shift, 0, (size_t)3 * F * 4, stream));
+    for (int l = 0; l < (linear ? 2 : 3); ++l) {
         HIP_TRY(hipMemcpyAsync(s->bias + (size_t)l * F, d->b[l], (size_t)F * 4, hipMemcpyDeviceToDevice, stream));
-        wide_scale_kernel<<<grid_for(F), 256, 0, stream>>>(d->bn_shift[l], kLog2e, F, s->shift + (size_t)l * F);
+        if (!linear) wide_scale_kernel<<<grid_for(F), 256, 0, stream>>>(d->bn_shift[l], kLog2e, F, s->shift + (size_t)l * F);
     }
     HIP_TRY(hipMemcpyAsync(s->bias + (size_t)3 * F, d->b4, (size_t)C * 4, hipMemcpyDeviceToDevice, stream));
+    // per-step epilogue scale: gamma * bn_scale * log2e (softplus in log2 units) or plain gamma (linear head)
     wide_pack_gamma_kernel<<<grid_for((long long)d->n_embed * 3 * F), 256, 0, stream>>>(
-        d->gamma[0], d->gamma[1], d->gamma[2], d->bn_scale[0], d->bn_scale[1], d->bn_scale[2], d->n_embed, F, s->gtab);
+        d->gamma[0], d->gamma[1], linear ? nullptr : d->gamma[2], linear ? nullptr : d->bn_scale[0],
+        linear ? nullptr : d->bn_scale[1], linear ? nullptr : d->bn_scale[2], linear ? 1.0f : kLog2e, d->n_embed, F, s->gtab);
     HIP_TRY(hipGetLastError());
     return CARD_OK;
 }
@@ -346,6 +358,12 @@ int wide_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     auto forward = [&](int t) -> int {
         const float* g = s->gtab + (size_t)t * 3 * F;
         int rc;
+        if (s->variant == CARD_VARIANT_LINEAR_HADAMARD) {
+            // lin3( gamma2 * lin2( linx(z) * (gamma1 * lin1(S)) ) ), imagenet/card/builder.py:86-92
+            if ((rc = gemm(EPI_SCALE_MUL, w.S, s->W1, b1, g, s->shift, r.x, r.n_z, w.hA, N, Kp, F, F, stream))) return rc;
+            if ((rc = gemm(EPI_SCALE, w.hA, s->W2, b2, g + F, s->shift + F, nullptr, 1, w.hB, N, F, F, F, stream))) return rc;
+            return gemm(EPI_BIAS, w.hB, s->W4, b4, nullptr, nullptr, nullptr, 1, w.eps, N, F, Cpad, Cpad, stream);
+        }
         if ((rc = gemm(EPI_SOFTPLUS_MUL, w.S, s->W1, b1, g, s->shift, r.x, r.n_z, w.hA, N, Kp, F, F, stream))) return rc;
         if ((rc = gemm(EPI_SOFTPLUS, w.hA, s->W2, b2, g + F, s->shift + F, nullptr, 1, w.hB, N, F, F, F, stream))) return rc;
         if ((rc = gemm(EPI_SOFTPLUS, w.hB, s->W3, b3, g + 2 * (size_t)F, s->shift + 2 * (size_t)F, nullptr, 1, w.hA, N, F, F, F, stream))) return rc;

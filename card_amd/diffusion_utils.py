@@ -54,7 +54,7 @@ def extract(input, t, x):
 
 def _model_x(model, s, x):
     """What the kernels take as `x`: x itself (regression) or the hoisted encoder features (classification)."""
-    return x_features(model, x) if s.variant == _lib.VARIANT_BN_HADAMARD else x
+    return x_features(model, x) if s.variant != _lib.VARIANT_GUIDED else x
 
 
 def _fresh_seed():

@@ -77,7 +77,7 @@ class Sampler:
         d.struct_bytes = C.sizeof(_lib.ModelDesc)
         d.variant, d.x_dim, d.y_dim, d.hidden, d.n_embed = variant, self.x_dim, self.y_dim, self.hidden, self.n_embed
         d.cat_x, d.cat_y_pred = int(self.cat_x), int(self.cat_y_pred)
-        for i in range(3):
+        for i in range(len(W)):
             d.W[i] = dev(W[i]).data_ptr()
             d.b[i] = dev(b[i]).data_ptr()
             d.gamma[i] = dev(gamma[i]).data_ptr()
@@ -127,6 +127,18 @@ class Sampler:
                    W=[sd[f"lin{i}.lin.weight"] for i in (1, 2, 3)], b=[sd[f"lin{i}.lin.bias"] for i in (1, 2, 3)],
                    gamma=[sd[f"lin{i}.embed.weight"] for i in (1, 2, 3)], W4=sd["lin4.weight"], b4=sd["lin4.bias"],
                    bn_scale=scale, bn_shift=shift, device=device)
+
+    @classmethod
+    def from_imagenet_head_state_dict(cls, sd, *, guidance=True, device):
+        """ImageNet theta head (classification/imagenet/card/builder.py:69-92): lin1, lin2 conditional, lin3 plain.
+        `x` of run() is then linx(z) (N, F), the step-invariant feature projection."""
+        W1 = sd["lin1.lin.weight"]
+        C, F = int(sd["lin3.weight"].shape[0]), int(W1.shape[0])
+        return cls(variant=_lib.VARIANT_LINEAR_HADAMARD, x_dim=F, y_dim=C, hidden=F,
+                   n_embed=int(sd["lin1.embed.weight"].shape[0]), cat_x=False, cat_y_pred=guidance,
+                   W=[sd["lin1.lin.weight"], sd["lin2.lin.weight"]], b=[sd["lin1.lin.bias"], sd["lin2.lin.bias"]],
+                   gamma=[sd["lin1.embed.weight"], sd["lin2.embed.weight"]], W4=sd["lin3.weight"], b4=sd["lin3.bias"],
+                   device=device)
 
     def _workspace(self, N):
         """(tensor, ptr, bytes) scratch for N rows: card_sampler_workspace_bytes (0 bytes for GUIDED)."""
@@ -241,15 +253,24 @@ def _is_cls(model):
 _xfeat_cache = weakref.WeakKeyDictionary()
 
 
+def _imagenet_theta(model):
+    # classification/imagenet/card/builder.py: the CARD wrapper (:8, model_theta attribute) or the bare head (:69)
+    theta = getattr(model, "model_theta", model)
+    ok = all(hasattr(theta, n) for n in ("linx", "lin1", "lin2", "lin3")) and not hasattr(theta, "lin4")
+    return theta if ok else None
+
+
 def x_features(model, x):
-    """x_feat = norm(encoder_x(x)) (classification/model.py:80-81), computed ONCE per distinct x tensor instead
-    of once per timestep: in eval mode it does not depend on t or y.  Stock PyTorch-ROCm (out of scope to fuse)."""
+    """x_feat = norm(encoder_x(x)) (classification/model.py:80-81) or linx(z) (imagenet/card/builder.py:90), computed
+    ONCE per distinct x tensor instead of once per timestep: in eval mode it does not depend on t or y.
+    Stock PyTorch-ROCm (out of scope to fuse)."""
     key = (x.data_ptr(), x._version, tuple(x.shape), str(x.device)) + _fingerprint(model)
     hit = _xfeat_cache.get(model)
     if hit is not None and hit[0] == key:
         return hit[1]
+    theta = _imagenet_theta(model)
     with torch.no_grad():
-        xf = model.norm(model.encoder_x(x)).float().contiguous()
+        xf = (theta.linx(x) if theta is not None else model.norm(model.encoder_x(x))).float().contiguous()
     _xfeat_cache[model] = (key, xf)
     return xf
 
@@ -268,12 +289,16 @@ def sampler_for(model):
     if _is_guided(model):
         s = Sampler.from_state_dict(model.state_dict(), cat_x=bool(model.cat_x), cat_y_pred=bool(model.cat_y_pred),
                                     device=device)
+    elif _imagenet_theta(model) is not None:
+        theta = _imagenet_theta(model)
+        s = Sampler.from_imagenet_head_state_dict(theta.state_dict(), guidance=bool(getattr(theta, "guidance", True)),
+                                                  device=device)
     elif _is_cls(model):
         s = Sampler.from_cls_state_dict(model.state_dict(), guidance=bool(getattr(model, "guidance", True)),
                                         bn_eps=float(model.unetnorm1.eps), device=device)
     else:
         raise CardError(f"card_amd does not recognise {type(model).__name__} as a CARD eps_theta network "
-                        "(expected regression ConditionalGuidedModel or classification ConditionalModel); "
+                        "(expected regression ConditionalGuidedModel, classification ConditionalModel or the ImageNet head); "
                         "there is no eager fallback")
     _cache[model] = (fp, s)
     return s

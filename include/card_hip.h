@@ -43,7 +43,12 @@ typedef enum card_variant {
     CARD_VARIANT_GUIDED = 0,
     /* classification/model.py:22-94 ConditionalModel after the hoisted encoder: eval-BatchNorm after each
        ConditionalLinear and a Hadamard product with x_feat = norm(encoder_x(x)) after layer 1 */
-    CARD_VARIANT_BN_HADAMARD = 1
+    CARD_VARIANT_BN_HADAMARD = 1,
+    /* classification/imagenet/card/builder.py:69-92 ConditionalModel (ImageNet head): no BatchNorm, no softplus, two
+       conditional layers: lin2(gamma2[t]) o ( linx(z) * (gamma1[t] * lin1(cat(y_t, y_0_hat))) ) then lin3.
+       Descriptor: W/b/gamma[0] = lin1, [1] = lin2, [2] unused (NULL); W4/b4 = lin3; x = linx(z) (N, hidden), which
+       is step-invariant and therefore an input here. */
+    CARD_VARIANT_LINEAR_HADAMARD = 2
 } card_variant;
 
 typedef enum card_out_mode {

@@ -15,6 +15,7 @@ to the reference for a given injected noise tensor:
                               :37-51 (ConditionalGuidedModel.forward)
   * eps_theta (cls head)   <- classification/model.py:79-94 (ConditionalModel.forward,
                               eval-mode BatchNorm1d)
+  * eps_theta (ImageNet)   <- classification/imagenet/card/builder.py:54-92 (linear head, no BN/softplus)
   * p_sample               <- regression/diffusion_utils.py:57-90,
                               classification/diffusion_utils.py:54-87
   * p_sample_t_1to0        <- regression/diffusion_utils.py:94-104
@@ -186,9 +187,39 @@ def eps_theta_cls(w: ClsWeights, x_feat, y, y_0_hat, t: int):
     return F.linear(h, w.W4, w.b4)
 
 
+@dataclass
+class LinearHeadWeights:
+    """classification/imagenet/card/builder.py:69-92 ConditionalModel (ImageNet head): lin1, lin2 conditional,
+    lin3 plain, no activation / BatchNorm; `x_feat` = linx(z) is step-invariant and an input here."""
+    W: List[torch.Tensor]        # lin1 (F, 2C or C), lin2 (F, F)
+    b: List[torch.Tensor]
+    gamma: List[torch.Tensor]    # 2 x (n_steps, F)
+    W3: torch.Tensor             # (C, F)
+    b3: torch.Tensor
+    guidance: bool = True
+
+    @staticmethod
+    def from_state_dict(sd, guidance=True, dtype=torch.float32):
+        g = lambda k: sd[k].detach().cpu().to(dtype)
+        return LinearHeadWeights(W=[g("lin1.lin.weight"), g("lin2.lin.weight")], b=[g("lin1.lin.bias"), g("lin2.lin.bias")],
+                                 gamma=[g("lin1.embed.weight"), g("lin2.embed.weight")], W3=g("lin3.weight"),
+                                 b3=g("lin3.bias"), guidance=guidance)
+
+
+def eps_theta_linear_head(w: LinearHeadWeights, x_feat, y, y_0_hat, t: int):
+    """ConditionalModel.forward, classification/imagenet/card/builder.py:86-92, with linx(z) hoisted."""
+    h = torch.cat([y, y_0_hat], dim=-1) if w.guidance else y
+    h = _cond_linear(h, w.W[0], w.b[0], w.gamma[0], t)
+    h = x_feat * h
+    h = _cond_linear(h, w.W[1], w.b[1], w.gamma[1], t)
+    return F.linear(h, w.W3, w.b3)
+
+
 def eps_theta(w, x, y_t, y_0_hat, t: int):
     if isinstance(w, GuidedWeights):
         return eps_theta_guided(w, x, y_t, y_0_hat, t)
+    if isinstance(w, LinearHeadWeights):
+        return eps_theta_linear_head(w, x, y_t, y_0_hat, t)
     return eps_theta_cls(w, x, y_t, y_0_hat, t)
 
 

@@ -53,6 +53,48 @@ def load_reference():
     return reg_du, reg_model, cls_du, cls_model
 
 
+def load_imagenet_reference():
+    inet_du = _load("ref_inet_diffusion_utils", f"{REF}/classification/imagenet/card/diffusion_utils.py")
+    inet_builder = _load("ref_inet_builder", f"{REF}/classification/imagenet/card/builder.py")
+    return inet_du, inet_builder
+
+
+def gen_imagenet_head(inet_du, inet_builder, name, C, Fdim, T, N, seed):
+    """classification/imagenet: ConditionalModel(y_dim=C, feature_dim=F) driven through the tree's own
+    p_sample_loop (which calls model(x, y, t, yhat, mode='theta'), diffusion_utils.py:80): a thin module with
+    that call signature wraps model_theta exactly like builder.py:52-53 does."""
+    torch.manual_seed(seed)
+    theta = inet_builder.ConditionalModel(y_dim=C, feature_dim=Fdim, n_steps=T, guidance=True).eval()
+    with torch.no_grad():
+        theta.lin3.weight.mul_(0.1)
+        theta.lin3.bias.mul_(0.1)
+
+    class Wrap(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.model_theta = m
+
+        def forward(self, x, y, t, yhat=None, mode="theta"):
+            return self.model_theta(x, y, t, yhat)
+
+    model = Wrap(theta)
+    alphas, abs_, omabs = schedule(inet_du, "linear", T, 0.01, 0.95)      # imagenet/main.py:83-88 defaults
+    z = torch.randn(N, Fdim)
+    y0hat = torch.softmax(torch.randn(N, C) * 2, dim=1)
+    with torch.no_grad():
+        x_feat = theta.linx(z)
+    noise, seq = run_loop(inet_du, model, z, y0hat, y0hat, T, alphas, omabs, seed + 1)
+    traj = torch.stack(seq, 0)
+    assert torch.equal(seq[0], noise[0] + y0hat)
+    with torch.no_grad():
+        eps = theta(z, traj[T - 3], torch.tensor([3]), y0hat)
+    np.savez(os.path.join(OUT, name + ".npz"), kind="imagenet_head", T=T, seed=seed, z=z.numpy(), x_feat=x_feat.numpy(),
+             y0hat=y0hat.numpy(), yTmean=y0hat.numpy(), alphas=alphas.numpy(), alphas_bar_sqrt=abs_.numpy(),
+             omabs=omabs.numpy(), noise=noise.numpy(), traj_idx=np.arange(T + 1), traj=traj.numpy(),
+             probe_t=np.asarray([3]), **{"eps.t3": eps.numpy()}, **sd_arrays(theta))
+    print(f"{name}: N={N} T={T} C={C} F={Fdim} max|y|={traj.abs().max():.3f}")
+
+
 def schedule(du, name, T, b0, b1):
     # Diffusion.__init__, regression/card_regression.py:39-50
     betas = du.make_beta_schedule(schedule=name, num_timesteps=T, start=b0, end=b1).float()
@@ -242,6 +284,8 @@ def main():
                    keep_every=50, train_steps=4000)
     gen_classification(cls_du, cls_model, "cls_gaussmix_T50", "toy", 1, 3, 128, 50, 24, 21)
     gen_classification(cls_du, cls_model, "cls_mnist_T50", "MNIST", 784, 10, 128, 50, 20, 22)
+    inet_du, inet_builder = load_imagenet_reference()
+    gen_imagenet_head(inet_du, inet_builder, "inet_head_T10", 20, 128, 10, 24, 31)
 
 
 if __name__ == "__main__":

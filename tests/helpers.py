@@ -24,13 +24,17 @@ def load_golden(name):
     sd = {k[3:]: torch.from_numpy(v) for k, v in d.items() if k.startswith("sd.")}
     t = lambda k: torch.from_numpy(d[k])
     out = dict(raw=d, sd=sd, T=int(d["T"]), kind=str(d["kind"]),
-               x=t("x"), y0hat=t("y0hat"), yTmean=t("yTmean"), alphas=t("alphas"), omabs=t("omabs"),
+               x=t("x") if "x" in d else t("z"), y0hat=t("y0hat"), yTmean=t("yTmean"), alphas=t("alphas"), omabs=t("omabs"),
                alphas_bar_sqrt=t("alphas_bar_sqrt"), noise=t("noise"), traj=t("traj"),
                traj_idx=[int(i) for i in d["traj_idx"]], probe_t=[int(i) for i in d["probe_t"]])
     if out["kind"] == "regression":
         out["cat_x"], out["cat_y_pred"] = bool(d["cat_x"]), bool(d["cat_y_pred"])
         out["weights"] = orc.GuidedWeights.from_state_dict(sd, out["cat_x"], out["cat_y_pred"])
         out["x_in"] = out["x"]
+    elif out["kind"] == "imagenet_head":
+        out["weights"] = orc.LinearHeadWeights.from_state_dict(sd, guidance=True)
+        out["x_feat"] = t("x_feat")
+        out["x_in"] = out["x_feat"]
     else:
         out["weights"] = orc.ClsWeights.from_state_dict(sd, guidance=True)
         out["x_feat"] = t("x_feat")

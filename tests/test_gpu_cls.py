@@ -162,3 +162,39 @@ def test_cls_in_kernel_row_tiling():
     b = s.run(cuda(tile_rows(xf, n_z)), cuda(tile_rows(y0, n_z)), cuda(tile_rows(y0, n_z)), coef, T, seed=11,
               out_mode=_lib.OUT_ALL)
     assert a.shape == (T + 1, rows * n_z, y0.shape[1]) and torch.equal(a, b)
+
+
+def test_imagenet_linear_head_matches_reference():
+    """classification/imagenet/card/builder.py head (no BN / softplus, T = 10, beta 0.01..0.95) through the shim,
+    against the fixture generated by the ImageNet tree's own p_sample_loop."""
+    g = load_golden("inet_head_T10")
+    sd, T = g["sd"], g["T"]
+    F, d1 = sd["lin1.lin.weight"].shape
+    C, n = sd["lin3.weight"].shape[0], sd["lin1.embed.weight"].shape[0]
+
+    class Head(torch.nn.Module):           # attribute layout of builder.py:69-84
+        def __init__(self):
+            super().__init__()
+            self.guidance = True
+            self.linx = torch.nn.Linear(F, F)
+            self.lin1, self.lin2 = RefShapedCls.CL(d1, F, n), RefShapedCls.CL(F, F, n)
+            self.lin3 = torch.nn.Linear(F, C)
+            self.load_state_dict(sd)
+
+    class Card(torch.nn.Module):           # builder.py:8 wrapper: model(x, y, t, yhat, mode='theta')
+        def __init__(self):
+            super().__init__()
+            self.model_theta = Head()
+
+    m = Card().to(DEV).eval()
+    args = (m, cuda(g["x"]), cuda(g["y0hat"]), cuda(g["yTmean"]), T, cuda(g["alphas"]), cuda(g["omabs"]))
+    seq = card_amd.p_sample_loop(*args, noise=cuda(g["noise"]))
+    traj = torch.stack(seq, 0).cpu()
+    worst = max(norm_rel_err(traj[k], g["traj"][k]) for k in range(T + 1))
+    print(f"inet head: worst per-state norm-rel err {worst:.3e}")
+    assert worst <= TOL
+    y0 = card_amd.p_sample_loop(*args, True, noise=cuda(g["noise"]))     # imagenet/main.py:482 only_last_sample
+    assert torch.equal(y0.cpu(), traj[T])
+    s = card_amd.sampler_for(m)
+    eps = s.eps_theta(cuda(g["x_feat"]), cuda(g["traj"][T - 3]), cuda(g["y0hat"]), 3).cpu()
+    assert norm_rel_err(eps, g["raw"]["eps.t3"]) <= TOL
