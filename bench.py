@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 
 H = 128
 PEAK_FP32_MATRIX_TFLOPS = 157.3       # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-TILE_M, WAVES_PER_CU, TILES_PER_WAVE_PER_LAUNCH = 32, 8, 16   # launch_sampler() in card_amd/csrc/card_hip.hip
+TILE_M, WAVES_PER_CU, TILES_PER_WAVE_PER_LAUNCH = 32, 8, 16   # guided_run() chunking in card_amd/csrc/card_guided.hip
 
 
 # shape presets: name -> (rows per GPU, n_z, x_dim, description)
@@ -175,7 +175,7 @@ def main():
     if rank == 0:
         units = float(N) * T * a.steps * world
         value = units / elapsed
-        # dominant kernel = card_sample_guided_kernel; launches per step from launch_sampler()'s chunking
+        # dominant kernel = card_sample_guided_kernel; launches per step from guided_run()'s chunking
         cu = torch.cuda.get_device_properties(dev).multi_processor_count
         chunk = cu * WAVES_PER_CU * TILES_PER_WAVE_PER_LAUNCH * TILE_M
         launches = math.ceil(N / chunk) * a.steps
@@ -206,7 +206,7 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             threads = torch.get_num_threads()
-            rows_cpu, steps_cpu = 256 * 1000, 40      # one reference minibatch of toy_8gauss.yml (:67, :72)
+            rows_cpu, steps_cpu = 256 * 1000, 150     # one reference minibatch of toy_8gauss.yml (:67, :72)
             if a.workload != "toy":
                 rows_cpu = min(N, 64 * a.nz)          # one reference minibatch: testing.batch_size 64 x n_z
             v, dt = cpu_baseline(sd, x_dim, T, rows_cpu, steps_cpu, alphas, omabs)
