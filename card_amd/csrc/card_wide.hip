@@ -41,32 +41,33 @@ __global__ __launch_bounds__(256, 2) void wide_gemm_kernel(const float* __restri
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, hh = lane >> 5;
     const long long m0 = (long long)blockIdx.y * BM;
     const int n0 = blockIdx.x * BN;
-    // staging map: 8 threads cover one 128-byte row segment, 32 rows per pass, 4 passes per operand
+    // staging map: 8 threads cover one 128-byte row segment, 32 rows per pass, 4 passes per operand.  Both panels
+    // are read through buffer resources (base = this block's first row, scalar k offset): the k loop carries no
+    // per-lane address arithmetic, and rows past M read as zero (num_records) instead of being clamped.
     const int sr = tid >> 3, sc = (tid & 7) * 4;
-    const float* ap[4];
-    const float* wp[4];
+    const long long rows_a = M - m0 < BM ? M - m0 : BM;
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + m0 * K), 0, (int)(rows_a * K * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W + (long long)n0 * K), 0, BN * K * 4, 0x00020000);
+    int vo[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        long long r = m0 + sr + 32 * i;
-        if (r > M - 1) r = M - 1;                       // clamp: rows past M are computed but never stored
-        ap[i] = A + r * K + sc;
-        wp[i] = W + (long long)(n0 + sr + 32 * i) * K + sc;
-    }
+    for (int i = 0; i < 4; ++i) vo[i] = ((sr + 32 * i) * K + sc) * 4;
     f32x4 ra[4], rw[4];
     auto g_load = [&](int kt) {
+        const int so = kt * BK * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            ra[i] = *reinterpret_cast<const f32x4*>(ap[i] + kt * BK);
-            rw[i] = *reinterpret_cast<const f32x4*>(wp[i] + kt * BK);
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo[i], so, 0));
+            rw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, vo[i], so, 0));
         }
     };
+    float* const st_base = sm + sr * LDT + sc;
     auto s_store = [&](int st) {
-        float* As = sm + st * kStageFloats;
+        float* As = st_base + st * kStageFloats;
         float* Ws = As + BM * LDT;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(As + (sr + 32 * i) * LDT + sc) = ra[i];
-            *reinterpret_cast<f32x4*>(Ws + (sr + 32 * i) * LDT + sc) = rw[i];
+            *reinterpret_cast<f32x4*>(As + 32 * i * LDT) = ra[i];
+            *reinterpret_cast<f32x4*>(Ws + 32 * i * LDT) = rw[i];
         }
     };
     f32x16 acc[2][2];
@@ -77,15 +78,12 @@ __global__ __launch_bounds__(256, 2) void wide_gemm_kernel(const float* __restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-    const int nk = K / BK;
-    g_load(0);
-    s_store(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) g_load(kt + 1);
-        const float* As = sm + (kt & 1) * kStageFloats + (wm * 64 + li) * LDT + 4 * hh;
-        const float* Ws = sm + (kt & 1) * kStageFloats + BM * LDT + (wn * 64 + li) * LDT + 4 * hh;
+    const float* const a_base = sm + (wm * 64 + li) * LDT + 4 * hh;
+    const float* const w_base = sm + BM * LDT + (wn * 64 + li) * LDT + 4 * hh;
+    // one 32-deep k tile from LDS stage `st` (a literal at both call sites: every LDS offset is an immediate)
+    auto compute = [&](int st) {
+        const float* As = a_base + st * kStageFloats;
+        const float* Ws = w_base + st * kStageFloats;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(As + 8 * t);
@@ -100,7 +98,36 @@ __global__ __launch_bounds__(256, 2) void wide_gemm_kernel(const float* __restri
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
             }
         }
-        if (more) s_store((kt + 1) & 1);
+    };
+    const int nk = K / BK;
+    g_load(0);
+    s_store(0);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 2 <= nk; kt += 2) {                        // two k tiles per trip: stage 0 then stage 1
+        const bool more = kt + 2 < nk;
+        g_load(kt + 1);
+        compute(0);
+        s_store(1);
+        __syncthreads();
+        if (more) g_load(kt + 2);
+        compute(1);
+        if (more) s_store(0);
+        __syncthreads();
+    }
+    if (kt < nk) {                                         // odd tile count (layer 1: K = 32): last tile sits in stage 0
+        compute(0);
+        __syncthreads();
+    }
+    // Hadamard operand row of each chain row of this block (chain / n_z), one 64-bit division per row instead of
+    // one per element: table in LDS (the tiles are dead after the loop's last barrier)
+    int* mrow = reinterpret_cast<int*>(sm);
+    if (EPI == EPI_SOFTPLUS_MUL || EPI == EPI_SCALE_MUL) {
+        if (tid < BM) {
+            long long r = m0 + tid;
+            if (r > M - 1) r = M - 1;
+            mrow[tid] = (int)(r / mul_div);
+        }
         __syncthreads();
     }
     // epilogue: C/D map of the 32x32 tile: column = lane & 31 (feature), row = (r&3) + 8(r>>2) + 4(lane>>5) (chain)
@@ -114,12 +141,13 @@ __global__ __launch_bounds__(256, 2) void wide_gemm_kernel(const float* __restri
         for (int a = 0; a < 2; ++a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const long long row = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const int lr = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const long long row = m0 + lr;
                 float v = acc[a][b][r] + bb;
                 if (EPI == EPI_SOFTPLUS || EPI == EPI_SOFTPLUS_MUL) v = kLn2 * softplus_l2(fmaf(v, gg, ss));
                 if (EPI == EPI_SCALE || EPI == EPI_SCALE_MUL) v = gg * v;      // gamma[t] * lin(x), builder.py:63-65
                 if (row < M) {
-                    if (EPI == EPI_SOFTPLUS_MUL || EPI == EPI_SCALE_MUL) v *= mul[(row / mul_div) * ldo + col];   // Hadamard with x_feat (model.py:87)
+                    if (EPI == EPI_SOFTPLUS_MUL || EPI == EPI_SCALE_MUL) v *= mul[(long long)mrow[lr] * ldo + col];   // Hadamard with x_feat (model.py:87)
                     out[row * ldo + col] = v;
                 }
             }
