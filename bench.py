@@ -9,6 +9,9 @@ toy 8-Gaussians shape, 10 000 test rows x 1000 z-samples, x_dim=1 (d_in=3), H=12
 per GPU per step.  With N > 1 (torch.distributed.run, one rank per GPU, RCCL) every rank samples its own
 shard of rows (weak scaling, no data-path collective); the evaluation sums are all-reduced once per step.
 
+Other shapes of BASELINE.json's configs are presets (--workload boston | year | sweep | sweep256 | cifar10); networks
+other than the reference's H=128 / y_dim=1 regression MLP run on the streaming-GEMM back end.
+
 Rank 0 prints ONE JSON line with the driver contract's fields plus `roofline` and `cpu_baseline`.
 """
 import argparse
@@ -23,59 +26,43 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-H = 128
 PEAK_FP32_MATRIX_TFLOPS = 157.3       # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 TILE_M, WAVES_PER_CU, TILES_PER_WAVE_PER_LAUNCH = 32, 8, 16   # guided_run() chunking in card_amd/csrc/card_guided.hip
 
 
-# shape presets: name -> (rows per GPU, n_z, x_dim, description)
+# shape presets: name -> (kind, rows per GPU, n_z, x_dim, hidden, y_dim, description)
 WORKLOADS = {
-    "toy": (10_000, 1000, 1, "toy 8-Gaussians shape (BASELINE configs[1]: 10k test x, 1000 z-samples, toy_8gauss.yml)"),
-    "boston": (51, 100, 13, "UCI Boston plumbing shape (BASELINE configs[0]: 51 test rows x 100 z-samples, x_dim=13)"),
-    "year": (64_418, 200, 90, "UCI YearPredictionMSD shape, one GPU's 1/8 shard (BASELINE configs[2]: 515 345 rows / 8, "
-                              "200 z-samples, 90 features)"),
-    "sweep": (1_000_000, 100, 13, "synthetic 1M rows x 100 z-samples, x_dim=13, H=128 (BASELINE configs[4])"),
+    "toy": ("guided", 10_000, 1000, 1, 128, 1,
+            "toy 8-Gaussians shape (BASELINE configs[1]: 10k test x, 1000 z-samples, toy_8gauss.yml)"),
+    "boston": ("guided", 51, 100, 13, 128, 1,
+               "UCI Boston plumbing shape (BASELINE configs[0]: 51 test rows x 100 z-samples, x_dim=13)"),
+    "year": ("guided", 64_418, 200, 90, 128, 1,
+             "UCI YearPredictionMSD shape, one GPU's 1/8 shard (BASELINE configs[2]: 515 345 rows / 8, 200 z-samples, "
+             "90 features)"),
+    "sweep": ("guided", 1_000_000, 100, 13, 128, 1,
+              "synthetic 1M rows x 100 z-samples, x_dim=13, hidden 128 (BASELINE configs[4])"),
+    "sweep256": ("guided", 100_000, 100, 13, 256, 1,
+                 "synthetic rows x 100 z-samples, x_dim=13, hidden 256 (BASELINE configs[4], width-256 leg; 100k of the 1M "
+                 "rows per GPU by default, --rows 1000000 for all)"),
+    "cifar10": ("cls", 250, 100, 4096, 4096, 10,
+                "CIFAR-10 head shape (BASELINE configs[3]: F=4096, C=10, 100 z-samples; one reference test batch of 250 "
+                "images per GPU by default, cifar10.yml:66,:71; x_feat and y_0_hat synthetic)"),
 }
 
 
-def synth_state_dict(x_dim, T, seed=1234):
-    """Random-init weights of regression/model.py:21 ConditionalGuidedModel (nn.Linear default init, gamma
-    tables U(0,1) as regression/model.py:12, lin4 scaled x0.1 per SURVEY.md section 8d)."""
-    g = torch.Generator().manual_seed(seed)
-    d_in = x_dim + 2
-    sd = {}
-
-    def linear(name, i, o):
-        b = 1.0 / math.sqrt(i)
-        sd[name + ".weight"] = (torch.rand(o, i, generator=g) * 2 - 1) * b
-        sd[name + ".bias"] = (torch.rand(o, generator=g) * 2 - 1) * b
-
-    for k, i in (("lin1", d_in), ("lin2", H), ("lin3", H)):
-        linear(k + ".lin", i, H)
-        sd[k + ".embed.weight"] = torch.rand(T + 1, H, generator=g)
-    linear("lin4", H, 1)
-    sd["lin4.weight"] *= 0.1
-    sd["lin4.bias"] *= 0.1
-    return sd
-
-
-def cpu_baseline(sd, x_dim, T, rows, steps, alphas, omabs):
+def cpu_baseline(w, x, y0, T, steps, alphas, omabs):
     """The oracle (torch-CPU restatement, bit-equal to the reference here) timed on this host: `steps`
     timesteps of one reference-sized minibatch, noise drawn per step like the reference's randn_like."""
     from oracle import card_oracle as orc
-    w = orc.GuidedWeights.from_state_dict(sd)
-    g = torch.Generator().manual_seed(7)
-    x = torch.randn(rows, x_dim, generator=g)
-    y0 = torch.randn(rows, 1, generator=g)
     coef = orc.make_coef_table(alphas, omabs)
-    y = torch.randn(rows, 1) + y0
+    y = torch.randn_like(y0) + y0
     with torch.no_grad():
         y = orc.p_sample(w, x, y, y0, y0, T - 1, coef, torch.randn_like(y))   # warm-up
         t0 = time.perf_counter()
         for t in range(T - 2, T - 2 - steps, -1):
             y = orc.p_sample(w, x, y, y0, y0, t, coef, torch.randn_like(y))
         dt = time.perf_counter() - t0
-    return rows * steps / dt, dt
+    return y0.shape[0] * steps / dt, dt
 
 
 def main():
@@ -88,6 +75,7 @@ def main():
     ap.add_argument("--rows", type=int, default=None, help="test rows per GPU (default: preset)")
     ap.add_argument("--nz", type=int, default=None, help="z-samples per row (default: preset)")
     ap.add_argument("--x-dim", type=int, default=None)
+    ap.add_argument("--hidden", type=int, default=None, help="hidden width (128: persistent kernel; other multiples of 128: GEMM back end)")
     ap.add_argument("--T", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
@@ -112,37 +100,53 @@ def main():
 
     from card_amd import _lib
     from card_amd.sampler import Sampler, make_coef_table
+    from card_amd.synth import guided_state_dict, cls_state_dict
     from oracle.card_oracle import make_schedule   # schedule constructor only (host-side setup, not measured)
 
-    preset = WORKLOADS[a.workload]
-    a.rows = preset[0] if a.rows is None else a.rows
-    a.nz = preset[1] if a.nz is None else a.nz
-    a.x_dim = preset[2] if a.x_dim is None else a.x_dim
+    kind, p_rows, p_nz, p_xdim, p_hidden, y_dim, desc = WORKLOADS[a.workload]
+    a.rows = p_rows if a.rows is None else a.rows
+    a.nz = p_nz if a.nz is None else a.nz
+    a.x_dim = p_xdim if a.x_dim is None else a.x_dim
+    H = p_hidden if a.hidden is None else a.hidden
     T, x_dim = a.T, a.x_dim
     N = a.rows * a.nz
-    d_in = x_dim + 2
-    flops_per_unit = 2 * H * (d_in + 2 * H + 1)      # algorithmic flops per sample-step
-    sd = synth_state_dict(x_dim, T)
-    alphas, _, omabs = make_schedule("linear", T, 1e-4, 0.02)
-    sampler = Sampler.from_state_dict(sd, device=dev)
-    coef = make_coef_table(alphas, omabs).to(dev)
-
-    # synthetic test rows resident in HBM; the (row, z) tiling of regression/card_regression.py:1027-1035 is done
-    # inside the kernel (card_run_args.n_z)
     g = torch.Generator().manual_seed(1234 + rank)
-    x_rows = torch.randn(a.rows, x_dim, generator=g)
-    y0_rows = torch.randn(a.rows, 1, generator=g)
+    alphas, _, omabs = make_schedule("linear", T, 1e-4, 0.02)
+    coef = make_coef_table(alphas, omabs).to(dev)
+    if kind == "guided":
+        d_in = x_dim + 2
+        flops_per_unit = 2 * H * (d_in + 2 * H + 1)      # algorithmic flops per sample-step
+        sd = guided_state_dict(x_dim, T, hidden=H)
+        sampler = Sampler.from_state_dict(sd, device=dev)
+        # synthetic test rows resident in HBM; the (row, z) tiling of regression/card_regression.py:1027-1035 is done
+        # inside the kernel (card_run_args.n_z)
+        x_rows = torch.randn(a.rows, x_dim, generator=g)
+        y0_rows = torch.randn(a.rows, 1, generator=g)
+        y_true = (y0_rows + 0.3 * torch.randn(a.rows, 1, generator=g)).to(dev)
+    else:
+        H = x_dim                                        # F: x is x_feat = norm(encoder_x(x)), hoisted out of the loop
+        d_in = 2 * y_dim
+        flops_per_unit = 2 * H * (d_in + 2 * H + y_dim)  # theta only, encoder hoisted
+        sd = cls_state_dict(H, y_dim, T, 3)
+        sampler = Sampler.from_cls_state_dict(sd, device=dev)
+        x_rows = torch.randn(a.rows, H, generator=g)
+        y0_rows = torch.softmax(torch.randn(a.rows, y_dim, generator=g) * 2, 1)
+        y_true = None
+    persistent = kind == "guided" and H == 128
     x, y0 = x_rows.to(dev), y0_rows.to(dev)
-    elem_offset = rank * N
-    y_true = (y0_rows + 0.3 * torch.randn(a.rows, 1, generator=g)).to(dev)
+    elem_offset = rank * N * y_dim
     from card_amd.distributed import regression_metric_sums, all_reduce_sums
 
     def one_step(i):
         y = sampler.run(x, y0, y0, coef, T, seed=1234 + i, elem_offset=elem_offset, out_mode=_lib.OUT_LAST, n_z=a.nz)
         if use_dist:
-            # evaluation sums (n, squared error, PICP count, QICE bin counts: card_regression.py:776-821) of this
-            # rank's rows, then ONE 15-element RCCL all-reduce per loop -- the only collective on the path
-            sums = regression_metric_sums(y.reshape(a.rows, a.nz, 1), y_true)
+            # evaluation sums of this rank's rows, then ONE small RCCL all-reduce per loop -- the only collective
+            if kind == "guided":
+                # n, squared error, PICP count, QICE bin counts (card_regression.py:776-821): 15 numbers
+                sums = regression_metric_sums(y.reshape(a.rows, a.nz, 1), y_true)
+            else:
+                # predicted-label histogram of the per-image mean sample (card_classification.py:1010-1020)
+                sums = torch.bincount(y.reshape(a.rows, a.nz, y_dim).mean(1).argmax(1), minlength=y_dim).double()
             all_reduce_sums(sums)
         return y
 
@@ -175,16 +179,25 @@ def main():
     if rank == 0:
         units = float(N) * T * a.steps * world
         value = units / elapsed
-        # dominant kernel = card_sample_guided_kernel; launches per step from guided_run()'s chunking
-        cu = torch.cuda.get_device_properties(dev).multi_processor_count
-        chunk = cu * WAVES_PER_CU * TILES_PER_WAVE_PER_LAUNCH * TILE_M
-        launches = math.ceil(N / chunk) * a.steps
         ev_ms = ev0.elapsed_time(ev1)                      # HIP events on the launch stream, rank 0
+        if persistent:
+            # dominant (only) kernel = card_sample_guided_kernel; launches per step from guided_run()'s chunking
+            cu = torch.cuda.get_device_properties(dev).multi_processor_count
+            chunk = cu * WAVES_PER_CU * TILES_PER_WAVE_PER_LAUNCH * TILE_M
+            launches = math.ceil(N / chunk) * a.steps
+            kernel = "card_sample_guided_kernel"
+        else:
+            # GEMM back end: a timestep is 4 GEMM launches + 1 update launch per chunk of chains; the two F x F
+            # wide_gemm_kernel<EPI_SOFTPLUS> launches carry > 95 % of the flops.  `achieved` below still divides the
+            # algorithmic flops by the WHOLE timed region (every launch), so it is a lower bound for that kernel.
+            chunk = None
+            launches = 2 * T * a.steps
+            kernel = "wide_gemm_kernel<EPI_SOFTPLUS> (+ layer-1 / head GEMM and update launches, all inside the timed region)"
         avg_launch_ms = ev_ms / launches
         achieved = (float(N) * T * a.steps * flops_per_unit) / (ev_ms * 1e-3) / 1e12
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
+        if persistent and os.path.exists(tpath):
             tj = json.load(open(tpath))
             # measured for ONE full-size launch of the same shape (tools/profile_pmc.sh); valid when this run's
             # launches are that size too
@@ -195,21 +208,33 @@ def main():
             "value": value, "unit": "sample-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{preset[3]}: {a.rows} test rows x {a.nz} z-samples per GPU, x_dim={x_dim} "
-                                   f"(d_in={d_in}), H={H}, T={T}, in-kernel Philox noise, last-sample output, "
-                                   "random-init weights",
+            "config": {"workload": f"{desc}: {a.rows} test rows x {a.nz} z-samples per GPU, x_dim={x_dim} "
+                                   f"(d_in={d_in}), H={H}, y_dim={y_dim}, T={T}, in-kernel Philox noise, last-sample "
+                                   "output, random-init weights",
                        "rows_per_gpu": a.rows, "n_z": a.nz, "T": T, "sharding": f"rows x{world}, no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
-                         "kernel": "card_sample_guided_kernel", "flops_per_sample_step": flops_per_unit,
+                         "kernel": kernel, "flops_per_sample_step": flops_per_unit,
                          "launches": launches, "avg_launch_ms": avg_launch_ms},
         }
         if world == 1 and not a.no_cpu_baseline:
             threads = torch.get_num_threads()
-            rows_cpu, steps_cpu = 256 * 1000, 150     # one reference minibatch of toy_8gauss.yml (:67, :72)
-            if a.workload != "toy":
-                rows_cpu = min(N, 64 * a.nz)          # one reference minibatch: testing.batch_size 64 x n_z
-            v, dt = cpu_baseline(sd, x_dim, T, rows_cpu, steps_cpu, alphas, omabs)
+            from oracle import card_oracle as orc
+            gc = torch.Generator().manual_seed(7)
+            if kind == "guided":
+                rows_cpu, steps_cpu = 256 * 1000, 150     # one reference minibatch of toy_8gauss.yml (:67, :72)
+                if a.workload != "toy":
+                    rows_cpu = min(N, 64 * a.nz)          # one reference minibatch: testing.batch_size 64 x n_z
+                if H != 128:
+                    steps_cpu = 60
+                w = orc.GuidedWeights.from_state_dict(sd)
+                xc, yc = torch.randn(rows_cpu, x_dim, generator=gc), torch.randn(rows_cpu, 1, generator=gc)
+            else:
+                rows_cpu, steps_cpu = 2500, 4             # a tenth of one reference test batch (250 images x 100 z)
+                w = orc.ClsWeights.from_state_dict(sd)
+                xc = torch.randn(rows_cpu, H, generator=gc)
+                yc = torch.softmax(torch.randn(rows_cpu, y_dim, generator=gc) * 2, 1)
+            v, dt = cpu_baseline(w, xc, yc, T, steps_cpu, alphas, omabs)
             out["cpu_baseline"] = {"value": v, "unit": "sample-steps/s", "cores": threads, "kind": "port",
                                    "sample": f"{steps_cpu} of the {T} timesteps of one reference minibatch "
                                              f"({rows_cpu} chains), torch CPU fp32, {dt:.1f} s"}

@@ -9,6 +9,7 @@ from .diffusion_utils import (  # noqa: F401
     make_beta_schedule,
     p_sample,
     p_sample_loop,
+    p_sample_loop_with_eval,
     p_sample_t_1to0,
     q_sample,
     y_0_reparam,

@@ -25,6 +25,7 @@ struct card_sampler {
     int variant, x_dim, y_dim, hidden, n_embed, cat_x, cat_y_pred;
     int d_in;
     int device, num_cu;
+    int backend;   // 0: persistent kernel (card_guided.hip), 1: streaming GEMMs (card_wide.hip)
     // ---- CARD_VARIANT_GUIDED (card_guided.hip)
     int k1, hoist, nqs;
     float* wpk;    // packed LDS image
@@ -33,7 +34,7 @@ struct card_sampler {
     float* ws;     // hoist: per-wave scratch slots (num_cu * 8 * 16 KB)
     void (*kernel)(const struct GuidedParams);
     size_t lds_bytes;
-    // ---- CARD_VARIANT_BN_HADAMARD (card_wide.hip)
+    // ---- GEMM back end (card_wide.hip): BN_HADAMARD, LINEAR_HADAMARD, and GUIDED at hidden != 128 or y_dim != 1
     float* W1;     // (F, d_in)
     float* W2;     // (F, F)
     float* W3;     // (F, F)

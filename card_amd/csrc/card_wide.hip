@@ -159,16 +159,20 @@ __global__ __launch_bounds__(256, 2) void wide_gemm_kernel(const float* __restri
 // operand is the state matrix S (N x Kp): columns [0, C) hold y_t (rewritten every step by the update kernel),
 // columns [C, 2C) hold y_0_hat (guidance), the rest is zero.  This kernel writes the static columns once per run
 // and, when y_src is given, the y_t columns too.
-__global__ void wide_pack_state_kernel(const float* __restrict__ y_src, const float* __restrict__ yhat, int C,
-                                       int guidance, int Kp, int n_z, long long N, float* __restrict__ S) {
+__global__ void wide_pack_state_kernel(const float* __restrict__ y_src, const float* __restrict__ yhat,
+                                       const float* __restrict__ x, int C, int guidance, int x_cols, int Kp, int n_z,
+                                       long long N, float* __restrict__ S) {
     const long long total = N * Kp;
+    const int x0 = guidance ? 2 * C : C;               // GUIDED on this back end: cat(y_t, [y_0_hat], [x]), model.py:40-47
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long n = i / Kp;
         const int k = (int)(i - n * Kp);
         if (k < C) {
             if (y_src) S[i] = y_src[n * C + k];
+        } else if (guidance && k < 2 * C) {
+            S[i] = yhat[(n / n_z) * C + (k - C)];
         } else {
-            S[i] = (guidance && k < 2 * C) ? yhat[(n / n_z) * C + (k - C)] : 0.0f;
+            S[i] = (k - x0 < x_cols) ? x[(n / n_z) * x_cols + (k - x0)] : 0.0f;
         }
     }
 }
@@ -177,9 +181,9 @@ __global__ void wide_pack_state_kernel(const float* __restrict__ y_src, const fl
 __global__ void wide_init_kernel(const float* __restrict__ mu, const float* __restrict__ noise, unsigned long long seed,
                                  unsigned long long elem_offset, long long n_elems, int C, int Kp, int n_z,
                                  float* __restrict__ S, float* __restrict__ out, const int* __restrict__ state_slot,
-                                 long long fixed_slot) {
+                                 long long fixed_slot, long long slot_stride) {
     const long long slot = state_slot ? (long long)state_slot[0] : fixed_slot;
-    float* out0 = slot >= 0 ? out + slot * n_elems : nullptr;
+    float* out0 = slot >= 0 ? out + slot * slot_stride : nullptr;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_elems;
          i += (long long)gridDim.x * blockDim.x) {
         float z;
@@ -203,9 +207,10 @@ __global__ void wide_update_kernel(const float* __restrict__ eps, int ld_eps, co
                                    const float* __restrict__ coef_row, const float* __restrict__ noise_d,
                                    unsigned long long seed, unsigned long long elem_offset, int draw, int t, int C,
                                    long long n_elems, int Kp, int n_z, float* __restrict__ S, float* __restrict__ out,
-                                   const int* __restrict__ state_slot, int state, long long fixed_slot) {
+                                   const int* __restrict__ state_slot, int state, long long fixed_slot,
+                                   long long slot_stride) {
     const long long slot = state_slot ? (long long)state_slot[state] : fixed_slot;
-    float* out_slot = slot >= 0 ? out + slot * n_elems : nullptr;
+    float* out_slot = slot >= 0 ? out + slot * slot_stride : nullptr;
     const float c_inv = coef_row[CARD_COEF_INV_SQRT_AB], c_om = coef_row[CARD_COEF_ONE_M_SQRT_AB];
     const float c_s = coef_row[CARD_COEF_SOMAB], g0 = coef_row[CARD_COEF_G0], g1 = coef_row[CARD_COEF_G1];
     const float g2 = coef_row[CARD_COEF_G2], sig = coef_row[CARD_COEF_SIGMA];
@@ -314,17 +319,31 @@ int gemm(int epi, const float* A, const float* W, const float* bias, const float
 
 }  // namespace
 
+// A run works through the batch in chunks of as many chains as the workspace holds (chunks start on a row
+// boundary when rows are tiled in-kernel), so the workspace never has to grow with N: the size reported here
+// covers min(N, ~4 GiB worth of chains), enough rounds of GEMM tiles per launch to fill the chip.
+namespace {
+inline size_t per_chain_bytes(const card_sampler* s) {
+    const int Cpad = (s->y_dim + BN - 1) / BN * BN;
+    return ((size_t)2 * s->hidden + Cpad + state_ld(s)) * 4;
+}
+inline long long gcd_ll(long long a, long long b) { while (b) { long long t = a % b; a = b; b = t; } return a; }
+}  // namespace
+
 unsigned long long wide_workspace_bytes(const card_sampler* s, long long N) {
     const int Cpad = (s->y_dim + BN - 1) / BN * BN;
-    return carve(nullptr, N, s->hidden, state_ld(s), Cpad).bytes;
+    long long chunk = (long long)((4ULL << 30) / per_chain_bytes(s)) / 16000 * 16000;   // multiple of 128 and of n_z = 100, 1000
+    if (chunk < 16000) chunk = 16000;
+    return carve(nullptr, N < chunk ? N : chunk, s->hidden, state_ld(s), Cpad).bytes;
 }
 
 int wide_create(card_sampler* s, const card_model_desc* d, hipStream_t stream) {
     const int F = d->hidden, C = d->y_dim;
-    if (F < 128 || F % 128) return card_fail(CARD_E_UNSUPPORTED, "card_sampler_create: BN_HADAMARD hidden=%d must be a multiple of 128", F);
-    if (d->x_dim != F) return card_fail(CARD_E_INVALID, "card_sampler_create: BN_HADAMARD x_dim (%d) must equal hidden (%d): x is x_feat", d->x_dim, F);
+    if (F < 128 || F % 128) return card_fail(CARD_E_UNSUPPORTED, "card_sampler_create: GEMM back end: hidden=%d must be a multiple of 128", F);
+    const bool guided = d->variant == CARD_VARIANT_GUIDED;            // regression/model.py:37-51 at widths the persistent kernel lacks
+    if (!guided && d->x_dim != F) return card_fail(CARD_E_INVALID, "card_sampler_create: BN_HADAMARD x_dim (%d) must equal hidden (%d): x is x_feat", d->x_dim, F);
     const bool linear = d->variant == CARD_VARIANT_LINEAR_HADAMARD;   // imagenet/card/builder.py:69-92
-    for (int l = 0; l < 3 && !linear; ++l)
+    for (int l = 0; l < 3 && !linear && !guided; ++l)
         if (!d->bn_scale[l] || !d->bn_shift[l]) return card_fail(CARD_E_INVALID, "card_sampler_create: BN_HADAMARD needs bn_scale/bn_shift (layer %d)", l + 1);
     const int d1 = s->d_in, Cpad = (C + BN - 1) / BN * BN;
     const size_t FF = (size_t)F * F;
@@ -350,13 +369,14 @@ int wide_create(card_sampler* s, const card_model_desc* d, hipStream_t stream) {
     HIP_TRY(hipMemsetAsync(s->shift, 0, (size_t)3 * F * 4, stream));
     for (int l = 0; l < (linear ? 2 : 3); ++l) {
         HIP_TRY(hipMemcpyAsync(s->bias + (size_t)l * F, d->b[l], (size_t)F * 4, hipMemcpyDeviceToDevice, stream));
-        if (!linear) wide_scale_kernel<<<grid_for(F), 256, 0, stream>>>(d->bn_shift[l], kLog2e, F, s->shift + (size_t)l * F);
+        if (!linear && !guided) wide_scale_kernel<<<grid_for(F), 256, 0, stream>>>(d->bn_shift[l], kLog2e, F, s->shift + (size_t)l * F);
     }
     HIP_TRY(hipMemcpyAsync(s->bias + (size_t)3 * F, d->b4, (size_t)C * 4, hipMemcpyDeviceToDevice, stream));
     // per-step epilogue scale: gamma * bn_scale * log2e (softplus in log2 units) or plain gamma (linear head)
     wide_pack_gamma_kernel<<<grid_for((long long)d->n_embed * 3 * F), 256, 0, stream>>>(
-        d->gamma[0], d->gamma[1], linear ? nullptr : d->gamma[2], linear ? nullptr : d->bn_scale[0],
-        linear ? nullptr : d->bn_scale[1], linear ? nullptr : d->bn_scale[2], linear ? 1.0f : kLog2e, d->n_embed, F, s->gtab);
+        d->gamma[0], d->gamma[1], linear ? nullptr : d->gamma[2], (linear || guided) ? nullptr : d->bn_scale[0],
+        (linear || guided) ? nullptr : d->bn_scale[1], (linear || guided) ? nullptr : d->bn_scale[2], linear ? 1.0f : kLog2e,
+        d->n_embed, F, s->gtab);
     HIP_TRY(hipGetLastError());
     return CARD_OK;
 }
@@ -367,22 +387,21 @@ void wide_destroy(card_sampler* s) {
         if (b) (void)hipFree(b);
 }
 
-int wide_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
+namespace {
+// one chunk of chains [c0, c0 + r.N): r holds chunk-local pointers; `stride` = (chains of the whole run) * C is the
+// distance between consecutive draws of `noise` and consecutive slots of `out`
+int wide_run_chunk(const card_sampler* s, const CardRun& r, long long stride, hipStream_t stream) {
     const int F = s->hidden, C = s->y_dim, Cpad = (C + BN - 1) / BN * BN;
     const long long N = r.N, ne = N * C;
-    const unsigned long long need = wide_workspace_bytes(s, N);
-    if (!r.workspace || r.workspace_bytes < need)
-        return card_fail(CARD_E_INVALID, "card_sampler_run: BN_HADAMARD needs a %llu-byte workspace (card_sampler_workspace_bytes), got %llu",
-                         need, r.workspace ? r.workspace_bytes : 0ULL);
-    if (((uintptr_t)r.workspace & 255) != 0) return card_fail(CARD_E_INVALID, "card_sampler_run: workspace must be 256-byte aligned");
     const int Kp = state_ld(s);
     const WideWs w = carve(r.workspace, N, F, Kp, Cpad);
     const float* b1 = s->bias;
     const float* b2 = s->bias + F;
     const float* b3 = s->bias + 2 * (size_t)F;
     const float* b4 = s->bias + 3 * (size_t)F;
+    const bool guided = s->variant == CARD_VARIANT_GUIDED;
 
-    // one eps_theta forward from the state matrix S (y_t | y_0_hat | 0) at timestep t -> w.eps (N x Cpad)
+    // one eps_theta forward from the state matrix S (y_t | y_0_hat | [x] | 0) at timestep t -> w.eps (N x Cpad)
     auto forward = [&](int t) -> int {
         const float* g = s->gtab + (size_t)t * 3 * F;
         int rc;
@@ -392,13 +411,14 @@ int wide_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
             if ((rc = gemm(EPI_SCALE, w.hA, s->W2, b2, g + F, s->shift + F, nullptr, 1, w.hB, N, F, F, F, stream))) return rc;
             return gemm(EPI_BIAS, w.hB, s->W4, b4, nullptr, nullptr, nullptr, 1, w.eps, N, F, Cpad, Cpad, stream);
         }
-        if ((rc = gemm(EPI_SOFTPLUS_MUL, w.S, s->W1, b1, g, s->shift, r.x, r.n_z, w.hA, N, Kp, F, F, stream))) return rc;
+        if ((rc = gemm(guided ? EPI_SOFTPLUS : EPI_SOFTPLUS_MUL, w.S, s->W1, b1, g, s->shift, r.x, r.n_z, w.hA, N, Kp, F, F, stream))) return rc;
         if ((rc = gemm(EPI_SOFTPLUS, w.hA, s->W2, b2, g + F, s->shift + F, nullptr, 1, w.hB, N, F, F, F, stream))) return rc;
         if ((rc = gemm(EPI_SOFTPLUS, w.hB, s->W3, b3, g + 2 * (size_t)F, s->shift + 2 * (size_t)F, nullptr, 1, w.hA, N, F, F, F, stream))) return rc;
         return gemm(EPI_BIAS, w.hA, s->W4, b4, nullptr, nullptr, nullptr, 1, w.eps, N, F, Cpad, Cpad, stream);
     };
     // static columns of S (+ y_t when the caller supplies it)
-    wide_pack_state_kernel<<<grid_for(N * Kp), 256, 0, stream>>>(r.y_init, r.y0hat, C, s->cat_y_pred, Kp, r.n_z, N, w.S);
+    wide_pack_state_kernel<<<grid_for(N * Kp), 256, 0, stream>>>(r.y_init, r.y0hat, guided ? r.x : nullptr, C, s->cat_y_pred,
+                                                                (guided && s->cat_x) ? s->x_dim : 0, Kp, r.n_z, N, w.S);
     HIP_TRY(hipGetLastError());
 
     if (r.eps_only) {
@@ -414,21 +434,57 @@ int wide_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     auto fixed = [&](int state) -> long long { return r.out_mode == CARD_OUT_ALL ? state - base : -1; };
     if (!r.y_init) {
         wide_init_kernel<<<grid_for(ne), 256, 0, stream>>>(r.ytmean, r.noise, r.seed, r.elem_offset, ne, C, Kp, r.n_z, w.S,
-                                                          r.out, sel, fixed(0));
+                                                          r.out, sel, fixed(0), stride);
         HIP_TRY(hipGetLastError());
     }
     for (int t = r.t_hi; t >= r.t_lo; --t) {
         if (int rc = forward(t)) return rc;
         const int draw = T - t;
-        const float* nz = (r.noise && t >= 1) ? r.noise + (long long)(draw - base) * ne : nullptr;
+        const float* nz = (r.noise && t >= 1) ? r.noise + (long long)(draw - base) * stride : nullptr;
         wide_update_kernel<<<grid_for(ne), 256, 0, stream>>>(w.eps, Cpad, r.ytmean, r.coef + (size_t)t * CARD_COEF_COLS, nz,
                                                             r.seed, r.elem_offset, draw, t, C, ne, Kp, r.n_z, w.S, r.out, sel, T - t,
-                                                            fixed(T - t));
+                                                            fixed(T - t), stride);
         HIP_TRY(hipGetLastError());
     }
     if (r.out_mode == CARD_OUT_LAST) {
         wide_copy_eps_kernel<<<grid_for(ne), 256, 0, stream>>>(w.S, Kp, C, ne, r.out);   // y_t columns of S -> (N, C)
         HIP_TRY(hipGetLastError());
+    }
+    return CARD_OK;
+}
+}  // namespace
+
+int wide_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
+    const int C = s->y_dim, nz = r.n_z;
+    const long long N = r.N;
+    if (!r.workspace) return card_fail(CARD_E_INVALID, "card_sampler_run: this model runs on the GEMM back end and needs a workspace (card_sampler_workspace_bytes)");
+    if (((uintptr_t)r.workspace & 255) != 0) return card_fail(CARD_E_INVALID, "card_sampler_run: workspace must be 256-byte aligned");
+    // chains per chunk: what the workspace holds, cut to whole 128-row GEMM tiles and whole input rows
+    const size_t pc = per_chain_bytes(s);
+    const int Cpad = (C + BN - 1) / BN * BN;
+    const bool fits = carve(nullptr, N, s->hidden, state_ld(s), Cpad).bytes <= r.workspace_bytes;
+    const long long cap = r.workspace_bytes > 4 * 256 ? (long long)((r.workspace_bytes - 4 * 256) / pc) : 0;   // 4 buffers, 256-B aligned
+    long long chunk = N;
+    if (!fits) {
+        const long long L = (long long)nz / gcd_ll(nz, BM) * BM;        // lcm(n_z, 128)
+        chunk = cap >= L ? cap / L * L : cap / nz * nz;
+        if (chunk < 1)
+            return card_fail(CARD_E_INVALID, "card_sampler_run: workspace of %llu bytes holds %lld chains, fewer than one input row's n_z=%d "
+                             "(card_sampler_workspace_bytes reports a sufficient size)", r.workspace_bytes, cap, nz);
+    }
+    for (long long c0 = 0; c0 < N; c0 += chunk) {
+        CardRun c = r;
+        c.N = N - c0 < chunk ? N - c0 : chunk;
+        const long long row0 = c0 / nz;                                  // chunks start on an input-row boundary
+        const int xw = s->variant == CARD_VARIANT_GUIDED ? s->x_dim : s->hidden;
+        if (r.x) c.x = r.x + row0 * xw;
+        c.y0hat = r.y0hat + row0 * C;
+        if (r.ytmean) c.ytmean = r.ytmean + row0 * C;
+        if (r.y_init) c.y_init = r.y_init + c0 * C;
+        if (r.noise) c.noise = r.noise + c0 * C;
+        c.out = r.out + c0 * C;
+        c.elem_offset = r.elem_offset + (unsigned long long)c0 * C;
+        if (int rc = wide_run_chunk(s, c, N * C, stream)) return rc;
     }
     return CARD_OK;
 }

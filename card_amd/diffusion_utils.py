@@ -17,7 +17,7 @@ from .sampler import (coef_on_device, make_coef_table, sampler_for, x_features, 
                       _require_cuda)
 
 __all__ = ["make_beta_schedule", "extract", "q_sample", "p_sample", "p_sample_t_1to0", "p_sample_loop",
-           "y_0_reparam"]
+           "p_sample_loop_with_eval", "y_0_reparam"]
 
 
 def make_beta_schedule(schedule="linear", num_timesteps=1000, start=1e-5, end=1e-2):
@@ -147,3 +147,38 @@ def p_sample_loop(model, x, y_0_hat, y_T_mean, n_steps, alphas, one_minus_alphas
     out = list(seq.unbind(0))
     assert len(out) == T + 1
     return out
+
+
+def p_sample_loop_with_eval(model, x, y_0_hat, y_T_mean, n_steps, alphas, one_minus_alphas_bar_sqrt, on_state,
+                            *, num_ts=None, seed=None, elem_offset=0, n_z=1):
+    """classification/card_classification.py:628-654: sample on the fly and hand each requested state to
+    `on_state(cur_y, num_t)` as soon as it exists, without keeping the trajectory.  num_t counts like the
+    reference (1 <-> y_T, n_steps + 1 <-> y_0); `num_ts` = the num_t values to report (None: all of them, the
+    reference's `compute_metric_all_steps`).  Between two reported states the chain runs as ONE card_sampler_run
+    segment; the noise stream is keyed by (seed, element, draw), so the samples do not depend on where the
+    segments are cut.  Returns y_0."""
+    s = sampler_for(model)
+    T = int(n_steps)
+    coef = coef_on_device(alphas, one_minus_alphas_bar_sqrt, T, s.device)
+    seed = _fresh_seed() if seed is None else int(seed)
+    want = sorted(set(range(1, T + 2) if num_ts is None else (int(v) for v in num_ts)))
+    if want and not (1 <= want[0] and want[-1] <= T + 1):
+        raise CardError(f"p_sample_loop_with_eval: num_t values must lie in [1, {T + 1}]")
+    xx = _model_x(model, s, x)
+    kw = dict(seed=seed, elem_offset=elem_offset, n_z=n_z)
+    stops = [v - 1 for v in want if v - 1 >= 1]          # state indices >= 1 at which to stop
+    if not stops or stops[-1] != T:
+        stops.append(T)
+    first = stops[0]
+    pair = s.run(xx, y_0_hat, y_T_mean, coef, T, t_hi=T - 1, t_lo=T - first, out_mode=_lib.OUT_SELECT, states=[0, first], **kw)
+    if 1 in want:
+        on_state(pair[0], 1)
+    cur, at = pair[1], first
+    if at + 1 in want:
+        on_state(cur, at + 1)
+    for nxt in stops[1:]:
+        cur = s.run(xx, y_0_hat, y_T_mean, coef, T, t_hi=T - at - 1, t_lo=T - nxt, y_init=cur, **kw)
+        at = nxt
+        if at + 1 in want:
+            on_state(cur, at + 1)
+    return cur

@@ -91,6 +91,7 @@ class Sampler:
             # the pack kernels read `keep` asynchronously on the current stream; the caching allocator is
             # stream-ordered, so releasing them after this point is safe
         self._h = h
+        self.workspace_limit = None      # bytes; set to bound the GEMM back end's workspace (runs then go in chunks)
         self._destroy = L.card_sampler_destroy
         weakref.finalize(self, L.card_sampler_destroy, h)
 
@@ -141,14 +142,16 @@ class Sampler:
                    device=device)
 
     def _workspace(self, N):
-        """(tensor, ptr, bytes) scratch for N rows: card_sampler_workspace_bytes (0 bytes for GUIDED)."""
+        """(tensor, ptr, bytes) scratch for N chains: card_sampler_workspace_bytes (0 bytes on the persistent kernel;
+        bounded on the GEMM back end, which walks larger batches in chunks)."""
         nb = C.c_uint64()
         _lib.check(_lib.lib().card_sampler_workspace_bytes(self._h, N, C.byref(nb)), "card_sampler_workspace_bytes")
         if nb.value == 0:
             return None, C.c_void_p(0), 0
-        ws = torch.empty(nb.value + 256, dtype=torch.uint8, device=self.device)
+        nbytes = nb.value if self.workspace_limit is None else min(nb.value, int(self.workspace_limit))
+        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
         ptr = (ws.data_ptr() + 255) & ~255
-        return ws, C.c_void_p(ptr), nb.value
+        return ws, C.c_void_p(ptr), nbytes
 
     # ------------------------------------------------------------------------------------------
     def _prep(self, t, cols, name):

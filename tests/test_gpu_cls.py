@@ -1,8 +1,6 @@
 """GPU parity of the classification head (CARD_VARIANT_BN_HADAMARD, streaming-GEMM back end) against the
 reference's golden fixtures (F = 128: gaussmix toy C = 3, MNIST-linear C = 10) and, at the CIFAR-10 width
 (F = 4096, classification/configs/cifar10.yml:15-16), against the CPU oracle on seeded random weights."""
-import math
-
 import pytest
 import torch
 
@@ -10,6 +8,7 @@ import card_amd
 from card_amd import _lib
 from card_amd.sampler import Sampler, make_coef_table
 from oracle import card_oracle as orc
+from card_amd.synth import cls_state_dict
 from tests.helpers import golden_names, load_golden, norm_rel_err
 
 pytestmark = pytest.mark.gpu
@@ -105,34 +104,12 @@ def test_cls_rng_mode_and_ragged_rows():
         assert torch.isfinite(a).all()
 
 
-def _random_cls_sd(F, C, T, seed):
-    gen = torch.Generator().manual_seed(seed)
-    sd = {}
-
-    def lin(name, i, o, scale=1.0):
-        b = 1.0 / math.sqrt(i)
-        sd[name + ".weight"] = (torch.rand(o, i, generator=gen) * 2 - 1) * b * scale
-        sd[name + ".bias"] = (torch.rand(o, generator=gen) * 2 - 1) * b * scale
-
-    for k, i in (("lin1", 2 * C), ("lin2", F), ("lin3", F)):
-        lin(k + ".lin", i, F)
-        sd[k + ".embed.weight"] = torch.rand(T + 1, F, generator=gen)
-    lin("lin4", F, C, 0.1)
-    for i in (1, 2, 3):
-        sd[f"unetnorm{i}.weight"] = torch.rand(F, generator=gen) * 0.6 + 0.7
-        sd[f"unetnorm{i}.bias"] = torch.randn(F, generator=gen) * 0.2
-        sd[f"unetnorm{i}.running_mean"] = torch.randn(F, generator=gen) * 0.3
-        sd[f"unetnorm{i}.running_var"] = torch.rand(F, generator=gen) + 0.5
-        sd[f"unetnorm{i}.num_batches_tracked"] = torch.tensor(0)
-    return sd
-
-
 @pytest.mark.parametrize("F,C", [(4096, 10), (256, 100)])
 def test_cls_wide_widths_against_oracle(F, C):
     """CIFAR-10 width (F = 4096, C = 10) and a 100-class head: HIP vs the CPU oracle, seeded random weights.
     (Parity here is pinned by the oracle only: no reference-generated fixture can hold 2 x 64 MB of weights.)"""
     T, N = 6, 72
-    sd = _random_cls_sd(F, C, T, 3)
+    sd = cls_state_dict(F, C, T, 3)
     w = orc.ClsWeights.from_state_dict(sd)
     gen = torch.Generator().manual_seed(4)
     xf = torch.randn(N, F, generator=gen)
@@ -198,3 +175,22 @@ def test_imagenet_linear_head_matches_reference():
     s = card_amd.sampler_for(m)
     eps = s.eps_theta(cuda(g["x_feat"]), cuda(g["traj"][T - 3]), cuda(g["y0hat"]), 3).cpu()
     assert norm_rel_err(eps, g["raw"]["eps.t3"]) <= TOL
+
+
+@pytest.mark.parametrize("num_ts", [None, [1, 8, 9, 30, 51], [51], [17]])
+def test_loop_with_eval_hook_matches_full_trajectory(num_ts):
+    """classification/card_classification.py:628-654: states handed to the callback on the fly are bit-equal to
+    the same states of one full run with the same seed, wherever the segments are cut."""
+    g = load_golden("cls_mnist_T50")
+    m = RefShapedCls(g["sd"]).to(DEV).eval()
+    T = g["T"]
+    args = (m, cuda(g["x_feat"][:6]), cuda(g["y0hat"][:6]), cuda(g["yTmean"][:6]), T, cuda(g["alphas"]), cuda(g["omabs"]))
+    full = torch.stack(card_amd.p_sample_loop(*args, seed=42, n_z=7), 0)
+    seen = {}
+    y0 = card_amd.p_sample_loop_with_eval(*args, lambda y, num_t: seen.__setitem__(num_t, y.clone()), num_ts=num_ts,
+                                          seed=42, n_z=7)
+    want = list(range(1, T + 2)) if num_ts is None else num_ts
+    assert sorted(seen) == sorted(want)
+    for num_t, y in seen.items():
+        assert torch.equal(y, full[num_t - 1]), num_t
+    assert torch.equal(y0, full[T])

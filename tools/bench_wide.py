@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from card_amd import _lib
 from card_amd.sampler import Sampler, make_coef_table
 from oracle.card_oracle import make_schedule
-from tests.test_gpu_cls import _random_cls_sd
+from card_amd.synth import cls_state_dict
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=250); ap.add_argument("--nz", type=int, default=100)
@@ -19,7 +19,7 @@ ap.add_argument("--reps", type=int, default=2)
 a = ap.parse_args()
 a.N = a.rows * a.nz
 dev = "cuda:0"
-sd = _random_cls_sd(a.F, a.C, a.T, 3)
+sd = cls_state_dict(a.F, a.C, a.T, 3)
 s = Sampler.from_cls_state_dict(sd, device=dev)
 g = torch.Generator().manual_seed(1)
 xf = torch.randn(a.rows, a.F, generator=g).to(dev)          # x_feat per test image; chains tiled in-kernel (n_z)
