@@ -132,7 +132,7 @@ def main():
         x_rows = torch.randn(a.rows, H, generator=g)
         y0_rows = torch.softmax(torch.randn(a.rows, y_dim, generator=g) * 2, 1)
         y_true = None
-    persistent = kind == "guided" and H == 128
+    persistent = kind == "guided" and H in (128, 256)     # card_guided.hip / card_stream.hip; otherwise GEMM back end
     x, y0 = x_rows.to(dev), y0_rows.to(dev)
     elem_offset = rank * N * y_dim
     from card_amd.distributed import regression_metric_sums, all_reduce_sums
@@ -183,9 +183,9 @@ def main():
         if persistent:
             # dominant (only) kernel = card_sample_guided_kernel; launches per step from guided_run()'s chunking
             cu = torch.cuda.get_device_properties(dev).multi_processor_count
-            chunk = cu * WAVES_PER_CU * TILES_PER_WAVE_PER_LAUNCH * TILE_M
+            chunk = cu * WAVES_PER_CU * TILES_PER_WAVE_PER_LAUNCH * TILE_M if H == 128 else cu * 8 * 128   # guided_run / stream_run
             launches = math.ceil(N / chunk) * a.steps
-            kernel = "card_sample_guided_kernel"
+            kernel = "card_sample_guided_kernel" if H == 128 else "card_sample_stream_kernel"
         else:
             # GEMM back end: a timestep is 4 GEMM launches + 1 update launch per chunk of chains; the two F x F
             # wide_gemm_kernel<EPI_SOFTPLUS> launches carry > 95 % of the flops.  `achieved` below still divides the

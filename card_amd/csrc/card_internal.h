@@ -25,7 +25,7 @@ struct card_sampler {
     int variant, x_dim, y_dim, hidden, n_embed, cat_x, cat_y_pred;
     int d_in;
     int device, num_cu;
-    int backend;   // 0: persistent kernel (card_guided.hip), 1: streaming GEMMs (card_wide.hip)
+    int backend;   // 0: persistent kernel (card_guided.hip), 1: streaming GEMMs (card_wide.hip), 2: persistent kernel with streamed weights (card_stream.hip)
     // ---- CARD_VARIANT_GUIDED (card_guided.hip)
     int k1, hoist, nqs;
     float* wpk;    // packed LDS image
@@ -51,4 +51,9 @@ int wide_create(card_sampler* s, const card_model_desc* d, hipStream_t stream);
 void wide_destroy(card_sampler* s);
 int wide_run(const card_sampler* s, const CardRun& r, hipStream_t stream);
 unsigned long long wide_workspace_bytes(const card_sampler* s, long long N);
+
+bool stream_supports(const card_model_desc* d, int d_in);
+int stream_create(card_sampler* s, const card_model_desc* d, hipStream_t stream);
+void stream_destroy(card_sampler* s);
+int stream_run(const card_sampler* s, const CardRun& r, hipStream_t stream);
 #endif

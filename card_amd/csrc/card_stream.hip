@@ -1,0 +1,410 @@
+// card_stream.hip - persistent sampler kernel for regression ConditionalGuidedModel networks whose hidden
+// layers do not fit in LDS (hidden = 256: 2 x 256 KB of fp32 weights; BASELINE.json configs[4], width-256 leg).
+//
+// Same idea as card_guided.hip -- a wave owns its chains for all T timesteps, activations stay in registers in
+// the transposed (feature x chain) layout so that one layer's MFMA accumulators are the next layer's B operands
+// -- with two changes forced by the weight size:
+//   * weights are STREAMED: the three layers of a timestep are cut into 32 KB slabs (8 k-steps x all output
+//     features, already in A-fragment order in global memory, L2-resident) that every wave of the workgroup
+//     consumes in lockstep from a double-buffered LDS ring; slab i+1 is fetched global -> registers while
+//     slab i is computed, written to the other buffer, one barrier per slab.  The slab sequence is the same
+//     every timestep (layer 1 | layer 2 | layer 3), so the ring simply cycles.
+//   * tiles are 16 chains wide (v_mfma_f32_16x16x4_f32: D[feature 4g+r][chain n], lane = 16g + n): the
+//     256-feature activation vector of 16 chains is 64 VGPRs, the accumulators another 64, which leaves room
+//     for two waves per SIMD.  k-step ks of a hidden layer takes register ks of the previous layer's
+//     accumulators as its B operand, i.e. input feature 16(ks>>2) + 4g + (ks&3) from lane group g; that k order
+//     is baked into the packed weights.
+// Layer 1 runs on MFMA every step from its own slab(s) (K padded to 4*KS1); softplus in log2 units with ln2
+// folded into W2, W3, W4 exactly as in card_guided.hip; posterior update unfused fp32 in the reference's order.
+#include <type_traits>
+
+#include "card_internal.h"
+
+using namespace card;
+
+namespace {
+
+constexpr int kWaves = 8;          // 2 per SIMD, one workgroup per CU
+constexpr int kThreads = kWaves * 64;
+constexpr int kTile = 16;          // chains per wave tile
+constexpr int kSlabKs = 8;         // k-steps (of 4) per slab
+constexpr int kGroupsPerWg = 8;    // tile groups (128 chains) one workgroup walks per launch
+
+template <int H>
+struct Geo {
+    static constexpr int NT = H / 16;               // 16-feature output tiles
+    static constexpr int NQ = NT / 4;               // ds_read_b128 per k-step (4 tiles each)
+    static constexpr int KSH = H / 4;               // k-steps of a hidden layer
+    static constexpr int NSH = KSH / kSlabKs;       // slabs of a hidden layer
+    static constexpr int SLAB = kSlabKs * NT * 64;  // floats per slab
+    static constexpr int TABS = 4 * H + 4;          // b1 | b2 | b3 | W4*ln2 | b4 (+3 pad)
+    static constexpr int GROW = 3 * H;              // one timestep's gamma*log2e
+    static constexpr int LDS_FLOATS = 2 * SLAB + TABS + 2 * GROW;
+};
+
+}  // namespace
+
+struct StreamParams {
+    const float* wimg;    // (NS, SLAB) weight slabs in fragment order
+    const float* tabs;    // Geo::TABS floats
+    const float* gtab;    // (n_embed, 3, H) gamma * log2e
+    const float* coef;
+    const float* x;
+    const float* y0hat;
+    const float* ytmean;
+    const float* y_init;
+    const float* noise;
+    float* out;
+    const int* state_slot;
+    long long N, n_begin, n_end;
+    unsigned long long seed, elem_offset;
+    int T, t_hi, t_lo;
+    int x_dim, cat_x, cat_y_pred;
+    int out_mode, eps_only, n_z;
+};
+
+namespace {
+
+template <int H, int KS1>
+__global__ __launch_bounds__(kThreads, 2) void card_sample_stream_kernel(const StreamParams p) {
+    using G = Geo<H>;
+    constexpr int NT = G::NT, NQ = G::NQ, NSH = G::NSH, SLAB = G::SLAB;
+    constexpr int NS1 = (KS1 + kSlabKs - 1) / kSlabKs;
+    constexpr int NS = NS1 + 2 * NSH;                     // slabs per timestep
+    static_assert(SLAB == NQ * kThreads * 4, "one slab = NQ b128 per thread");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const wbuf = lds;
+    float* const tabs = lds + 2 * SLAB;
+    float* const gbuf = tabs + G::TABS;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, n = lane & 15;
+
+    // prologue: tables, gamma row of the first step, slab 0
+    for (int i = tid * 4; i < G::TABS; i += kThreads * 4)
+        *reinterpret_cast<f32x4*>(tabs + i) = *reinterpret_cast<const f32x4*>(p.tabs + i);
+    for (int i = tid; i < G::GROW; i += kThreads) gbuf[i] = p.gtab[(long long)p.t_hi * G::GROW + i];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i)
+        *reinterpret_cast<f32x4*>(wbuf + (i * kThreads + tid) * 4) = *reinterpret_cast<const f32x4*>(p.wimg + (i * kThreads + tid) * 4);
+    __syncthreads();
+
+    int cur = 0;      // LDS buffer holding the slab consumed next
+    int nxt = 1;      // index (in the per-timestep cycle) of the slab fetched next
+    int gcur = 0;     // gamma buffer of the current step
+    f32x4 stage[NQ];
+    // slabs come through a buffer resource with a scalar offset: no per-lane 64-bit addresses to keep (or spill)
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wimg), 0, NS * SLAB * 4, 0x00020000);
+    const int voff = tid * 16;
+    auto slab_fetch = [&]() {
+        const int so = nxt * (SLAB * 4);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i)
+            stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, so + i * kThreads * 16, 0));
+    };
+    auto slab_commit = [&]() {
+        float* dst = wbuf + (cur ^ 1) * SLAB + tid * 4;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) *reinterpret_cast<f32x4*>(dst + i * kThreads * 4) = stage[i];
+        __syncthreads();
+        cur ^= 1;
+        nxt = nxt + 1 == NS ? 0 : nxt + 1;
+    };
+
+    const float* const bl = tabs + 4 * g;
+    const float* const w4l = tabs + 3 * H + 4 * g;
+    const float b4 = tabs[4 * H];
+    const long long n_rows = p.n_end - p.n_begin;
+    const long long n_groups = (n_rows + kWaves * kTile - 1) / (kWaves * kTile);
+    const int iters = (int)((n_groups + gridDim.x - 1) / gridDim.x);   // same for every workgroup: barriers inside
+    const int T = p.T;
+    const int draw0 = p.y_init ? (T - p.t_hi) : 0;
+    const int slot_base = draw0;
+
+    for (int it = 0; it < iters; ++it) {
+        const long long group = (long long)it * gridDim.x + blockIdx.x;
+        const long long row = p.n_begin + (group * kWaves + wave) * kTile + n;
+        const bool valid = row < p.n_end;                      // workgroups past the end run on clamped chains
+        const long long rc = valid ? row : p.n_end - 1;
+        const long long rr = p.n_z > 1 ? rc / p.n_z : rc;
+        const float mu = p.ytmean[rr];
+        const float y0h = p.y0hat[rr];
+        const unsigned long long elem = p.elem_offset + (unsigned long long)rc;
+        // input column k of cat(y_t, [y_0_hat], [x]) (regression/model.py:38-47); column 0 is y_t
+        auto input_col = [&](int k) -> float {
+            if (k == 0) return 0.0f;
+            if (p.cat_y_pred && k == 1) return y0h;
+            const int xi = k - 1 - (p.cat_y_pred ? 1 : 0);
+            return (p.cat_x && xi < p.x_dim) ? p.x[rr * p.x_dim + xi] : 0.0f;
+        };
+        float xin[KS1];                                        // layer-1 B operands: k-step s takes column 4s + g
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) xin[s] = input_col(4 * s + g);
+
+        float zc[4];
+        uint32_t zblock = 0xFFFFFFFFu;
+        auto draw = [&](int d) -> float {
+            if (p.noise) return p.noise[(long long)(d - draw0) * p.N + rc];
+            const uint32_t blk = (uint32_t)d >> 2;
+            if (blk != zblock) {
+                philox_normal4(p.seed, elem, blk, zc);
+                zblock = blk;
+            }
+            return pick4(zc, d & 3);
+        };
+        auto store_state = [&](int s, float v) {
+            long long slot;
+            if (p.out_mode == CARD_OUT_ALL) slot = s - slot_base;
+            else if (p.out_mode == CARD_OUT_SELECT) slot = p.state_slot[s];
+            else return;
+            if (slot >= 0 && valid && g == 0) p.out[slot * p.N + row] = v;
+        };
+        float y;
+        if (p.y_init) {
+            y = p.y_init[rc];
+        } else {
+            y = draw(0) + mu;                                  // regression/diffusion_utils.py:109-110
+            store_state(0, y);
+        }
+
+        for (int t = p.t_hi; t >= p.t_lo; --t) {
+            // next gamma row: t-1, or t_hi again for the next group of chains
+            const int tn = t > p.t_lo ? t - 1 : p.t_hi;
+            f32x4 gn = {0.f, 0.f, 0.f, 0.f};
+            if (tid < G::GROW / 4) gn = *reinterpret_cast<const f32x4*>(p.gtab + (long long)tn * G::GROW + tid * 4);
+            const float z = (t >= 1 && !p.eps_only) ? draw(T - t) : 0.0f;
+            const float* const gl = gbuf + gcur * G::GROW + 4 * g;
+
+            f32x4 acc[NT];
+            float h[4 * NT];
+            auto load_bias = [&](int layer) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = lds4(bl + layer * H + 16 * j);
+            };
+            // NKS k-steps of the current slab: acc[j] += A(slab)[j][ks] * b[ks]
+            auto compute = [&](auto nks_tag, auto off_tag, const auto& b) {
+                constexpr int NKS = decltype(nks_tag)::value, OFF = decltype(off_tag)::value;
+                const float* wl = wbuf + cur * SLAB + lane * 4;
+                // A fragments one k-step ahead; the compiler barriers keep the scheduler from hoisting a whole slab's
+                // LDS reads (128 VGPRs) above the MFMAs
+                f32x4 a[2][NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) a[0][q] = lds4(wl + q * 256);
+#pragma unroll
+                for (int s = 0; s < NKS; ++s) {
+                    asm volatile("" ::: "memory");
+                    if (s + 1 < NKS) {
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) a[(s + 1) & 1][q] = lds4(wl + ((s + 1) * NQ + q) * 256);
+                    }
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[4 * q + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1][q][e], b[OFF + s], acc[4 * q + e], 0, 0, 0);
+                    }
+                }
+            };
+            auto epilogue = [&](int layer) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const f32x4 gm = lds4(gl + layer * H + 16 * j);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[4 * j + r] = softplus_l2(acc[j][r] * gm[r]);
+                }
+            };
+
+            // the NSH slabs of one hidden layer; slab S multiplies registers h[8S .. 8S+7]
+            auto hidden_slabs = [&](auto first) {
+                auto body = [&](auto self, auto S_tag) -> void {
+                    constexpr int S = decltype(S_tag)::value;
+                    if constexpr (S < NSH) {
+                        slab_fetch();
+                        compute(std::integral_constant<int, kSlabKs>{}, std::integral_constant<int, S * kSlabKs>{}, h);
+                        slab_commit();
+                        self(self, std::integral_constant<int, S + 1>{});
+                    }
+                };
+                body(body, first);
+            };
+            // ---- layer 1 (regression/model.py:48)
+            if (g == 0) xin[0] = y;
+            load_bias(0);
+            if constexpr (NS1 >= 1) { slab_fetch(); compute(std::integral_constant<int, (KS1 < 8 ? KS1 : 8)>{}, std::integral_constant<int, 0>{}, xin); slab_commit(); }
+            if constexpr (NS1 >= 2) { slab_fetch(); compute(std::integral_constant<int, (KS1 - 8 < 8 ? KS1 - 8 : 8)>{}, std::integral_constant<int, 8>{}, xin); slab_commit(); }
+            if constexpr (NS1 >= 3) { slab_fetch(); compute(std::integral_constant<int, (KS1 - 16 < 8 ? KS1 - 16 : 8)>{}, std::integral_constant<int, 16>{}, xin); slab_commit(); }
+            static_assert(NS1 <= 3, "layer 1 is built for at most 3 slabs (d_in <= 96)");
+            epilogue(0);
+            // ---- layers 2, 3 (:49-50)
+#pragma unroll
+            for (int layer = 1; layer <= 2; ++layer) {
+                load_bias(layer);
+                hidden_slabs(std::integral_constant<int, 0>{});
+                epilogue(layer);
+            }
+            // ---- lin4 (:51): per-lane partial over its 64 features, then across the four lane groups
+            float part = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const f32x4 w = lds4(w4l + 16 * j);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part = fmaf(h[4 * j + r], w[r], part);
+            }
+            part += __shfl_xor(part, 16, 64);
+            part += __shfl_xor(part, 32, 64);
+            const float eps = part + b4;
+
+            if (p.eps_only) {
+                if (valid && g == 0) p.out[row] = eps;
+            } else {
+                // posterior update, regression/diffusion_utils.py:83-89 (t >= 1) / :101-103 (t == 0)
+                const float* c = p.coef + (long long)t * CARD_COEF_COLS;
+                const float y0r = c[CARD_COEF_INV_SQRT_AB] * ((y - c[CARD_COEF_ONE_M_SQRT_AB] * mu) - eps * c[CARD_COEF_SOMAB]);
+                if (t >= 1) {
+                    const float yh = (c[CARD_COEF_G0] * y0r + c[CARD_COEF_G1] * y) + c[CARD_COEF_G2] * mu;
+                    y = yh + c[CARD_COEF_SIGMA] * z;
+                } else {
+                    y = y0r;
+                }
+                store_state(T - t, y);
+            }
+            // publish the next gamma row (read after the next step's first slab barrier)
+            if (tid < G::GROW / 4) *reinterpret_cast<f32x4*>(gbuf + (gcur ^ 1) * G::GROW + tid * 4) = gn;
+            gcur ^= 1;
+        }
+        if (p.out_mode == CARD_OUT_LAST && !p.eps_only && valid && g == 0) p.out[row] = y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// create-time packing
+// ------------------------------------------------------------------------------------------------
+// slab q of the per-timestep cycle, element ((s*NQ + jq)*64 + l)*4 + e  =  W[out][in] with
+//   out = 16(4jq + e) + (l & 15),  g = l >> 4,  ks = 8*S + s
+//   layer 1 (q < NS1):  in = 4ks + g (zero past d_in)
+//   layers 2, 3:        in = 16(ks >> 2) + 4g + (ks & 3), scaled by ln2 (inputs are softplus / ln2)
+__global__ void stream_pack_kernel(const float* __restrict__ W1, const float* __restrict__ W2, const float* __restrict__ W3,
+                                   int H, int d_in, int ns1, float* __restrict__ out) {
+    const int NT = H / 16, NQ = NT / 4, NSH = H / 32, SLAB = kSlabKs * NT * 64;
+    const long long total = (long long)(ns1 + 2 * NSH) * SLAB;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(idx / SLAB), r = (int)(idx % SLAB);
+        const int e = r & 3, l = (r >> 2) & 63, sq = r >> 8, jq = sq % NQ, s = sq / NQ;
+        const int o = 16 * (4 * jq + e) + (l & 15), g = l >> 4;
+        float v;
+        if (q < ns1) {
+            const int in = 4 * (kSlabKs * q + s) + g;
+            v = in < d_in ? W1[(long long)o * d_in + in] : 0.0f;
+        } else {
+            const int layer = (q - ns1) / NSH, S = (q - ns1) % NSH, ks = kSlabKs * S + s;
+            const int in = 16 * (ks >> 2) + 4 * g + (ks & 3);
+            v = (layer == 0 ? W2 : W3)[(long long)o * H + in] * kLn2;
+        }
+        out[idx] = v;
+    }
+}
+
+__global__ void stream_tabs_kernel(const float* b1, const float* b2, const float* b3, const float* W4, const float* b4,
+                                   int H, float* __restrict__ tabs) {
+    for (int i = threadIdx.x; i < H; i += blockDim.x) {
+        tabs[i] = b1[i];
+        tabs[H + i] = b2[i];
+        tabs[2 * H + i] = b3[i];
+        tabs[3 * H + i] = W4[i] * kLn2;
+    }
+    if (threadIdx.x < 4) tabs[4 * H + threadIdx.x] = threadIdx.x == 0 ? b4[0] : 0.0f;
+}
+
+__global__ void stream_gamma_kernel(const float* g1, const float* g2, const float* g3, int n_embed, int H,
+                                    float* __restrict__ gtab) {
+    const long long total = (long long)n_embed * 3 * H;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int f = (int)(idx % H), l = (int)((idx / H) % 3);
+        const long long t = idx / (3LL * H);
+        gtab[idx] = (l == 0 ? g1 : (l == 1 ? g2 : g3))[t * H + f] * kLog2e;
+    }
+}
+
+typedef void (*stream_kernel_t)(const StreamParams);
+
+// smallest built layer-1 depth (in k-steps of 4 input columns) that holds d_in
+int stream_ks1_for(int d_in) {
+    const int need = (d_in + 3) / 4;
+    for (int ks : {1, 2, 4, 8, 16, 24})
+        if (need <= ks) return ks;
+    return 0;
+}
+
+stream_kernel_t stream_kernel_for(int H, int ks1) {
+    if (H != 256) return nullptr;
+    switch (ks1) {
+        case 1: return card_sample_stream_kernel<256, 1>;
+        case 2: return card_sample_stream_kernel<256, 2>;
+        case 4: return card_sample_stream_kernel<256, 4>;
+        case 8: return card_sample_stream_kernel<256, 8>;
+        case 16: return card_sample_stream_kernel<256, 16>;
+        case 24: return card_sample_stream_kernel<256, 24>;
+        default: return nullptr;
+    }
+}
+
+}  // namespace
+
+bool stream_supports(const card_model_desc* d, int d_in) {
+    if (const char* ev = getenv("CARD_AMD_STREAM"))
+        if (ev[0] == '0') return false;                 // A/B: force the GEMM back end
+    return d->variant == CARD_VARIANT_GUIDED && d->y_dim == 1 && d->hidden == 256 && stream_ks1_for(d_in) != 0;
+}
+
+int stream_create(card_sampler* s, const card_model_desc* d, hipStream_t stream) {
+    const int H = d->hidden, d_in = s->d_in;
+    const int ks1 = stream_ks1_for(d_in);
+    stream_kernel_t kern = stream_kernel_for(H, ks1);
+    if (!kern) return card_fail(CARD_E_UNSUPPORTED, "card_sampler_create: no streamed kernel for hidden=%d d_in=%d", H, d_in);
+    const int ns1 = (ks1 + kSlabKs - 1) / kSlabKs, NSH = H / 32, SLAB = kSlabKs * (H / 16) * 64;
+    s->k1 = ks1;
+    s->kernel = reinterpret_cast<void (*)(const GuidedParams)>(kern);
+    s->lds_bytes = (size_t)(2 * SLAB + 4 * H + 4 + 2 * 3 * H) * sizeof(float);
+    HIP_TRY(hipMalloc(&s->wpk, (size_t)(ns1 + 2 * NSH) * SLAB * sizeof(float)));
+    HIP_TRY(hipMalloc(&s->w1s, (size_t)(4 * H + 4) * sizeof(float)));
+    HIP_TRY(hipMalloc(&s->gtab, (size_t)d->n_embed * 3 * H * sizeof(float)));
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
+    stream_pack_kernel<<<512, 256, 0, stream>>>(d->W[0], d->W[1], d->W[2], H, d_in, ns1, s->wpk);
+    stream_tabs_kernel<<<1, 256, 0, stream>>>(d->b[0], d->b[1], d->b[2], d->W4, d->b4, H, s->w1s);
+    stream_gamma_kernel<<<512, 256, 0, stream>>>(d->gamma[0], d->gamma[1], d->gamma[2], d->n_embed, H, s->gtab);
+    HIP_TRY(hipGetLastError());
+    return CARD_OK;
+}
+
+void stream_destroy(card_sampler* s) {
+    if (s->wpk) (void)hipFree(s->wpk);
+    if (s->w1s) (void)hipFree(s->w1s);
+    if (s->gtab) (void)hipFree(s->gtab);
+}
+
+int stream_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
+    StreamParams p;
+    memset(&p, 0, sizeof(p));
+    p.wimg = s->wpk; p.tabs = s->w1s; p.gtab = s->gtab; p.coef = r.coef; p.x = r.x; p.y0hat = r.y0hat; p.ytmean = r.ytmean;
+    p.y_init = r.y_init; p.noise = r.noise; p.out = r.out; p.state_slot = r.state_slot;
+    p.N = r.N; p.seed = r.seed; p.elem_offset = r.elem_offset;
+    p.T = r.T; p.t_hi = r.t_hi; p.t_lo = r.t_lo;
+    p.x_dim = s->x_dim; p.cat_x = s->cat_x; p.cat_y_pred = s->cat_y_pred;
+    p.out_mode = r.out_mode; p.eps_only = r.eps_only; p.n_z = r.n_z;
+    stream_kernel_t kern = reinterpret_cast<stream_kernel_t>(s->kernel);
+    // launches of at most num_cu workgroups x kGroupsPerWg groups x 128 chains: every workgroup walks the same
+    // number of groups (the kernel's barriers need that) and one launch stays well under a second
+    const long long group = kWaves * kTile;
+    const long long chunk = (long long)s->num_cu * kGroupsPerWg * group;
+    for (long long b = 0; b < p.N; b += chunk) {
+        p.n_begin = b;
+        p.n_end = b + chunk < p.N ? b + chunk : p.N;
+        const long long groups = (p.n_end - p.n_begin + group - 1) / group;
+        const long long grid = groups < s->num_cu ? groups : s->num_cu;
+        kern<<<dim3((unsigned)grid), dim3(kThreads), s->lds_bytes, stream>>>(p);
+        HIP_TRY(hipGetLastError());
+    }
+    return CARD_OK;
+}
