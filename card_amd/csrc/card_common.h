@@ -61,7 +61,9 @@ __device__ __forceinline__ float pick4(const float (&z)[4], int i) {
 __device__ __forceinline__ float softplus_l2(float xs) {
     const float e = __builtin_amdgcn_exp2f(xs);
     const float l = __builtin_amdgcn_logf(1.0f + e);
-    return xs > kSpThresh ? xs : l;
+    // xs > threshold ? xs : l as ONE v_med3_f32: l >= xs always (l = +inf once exp2 overflows), and l <= threshold
+    // (to an ulp) whenever xs <= threshold, so the median of (l, xs, threshold) is l below the threshold and xs above
+    return __builtin_amdgcn_fmed3f(l, xs, kSpThresh);
 }
 
 __device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }

@@ -6,9 +6,10 @@
 // -- with two changes forced by the weight size:
 //   * weights are STREAMED: the three layers of a timestep are cut into 32 KB slabs (8 k-steps x all output
 //     features, already in A-fragment order in global memory, L2-resident) that every wave of the workgroup
-//     consumes in lockstep from a double-buffered LDS ring; slab i+1 is fetched global -> registers while
-//     slab i is computed, written to the other buffer, one barrier per slab.  The slab sequence is the same
-//     every timestep (layer 1 | layer 2 | layer 3), so the ring simply cycles.
+//     consumes in lockstep from a three-buffer LDS ring; slab i+2 is fetched global -> registers while slab i
+//     is computed, one barrier per slab placed MID-slab so that no wave drains its MFMA queue around it and
+//     A fragments are prefetched straight across slab boundaries.  The slab sequence is the same every
+//     timestep (layer 1 | layer 2 | layer 3), so the ring simply cycles.
 //   * tiles are 16 chains wide (v_mfma_f32_16x16x4_f32: D[feature 4g+r][chain n], lane = 16g + n): the
 //     256-feature activation vector of 16 chains is 64 VGPRs, the accumulators another 64, which leaves room
 //     for two waves per SIMD.  k-step ks of a hidden layer takes register ks of the previous layer's
@@ -39,7 +40,8 @@ struct Geo {
     static constexpr int SLAB = kSlabKs * NT * 64;  // floats per slab
     static constexpr int TABS = 4 * H + 4;          // b1 | b2 | b3 | W4*ln2 | b4 (+3 pad)
     static constexpr int GROW = 3 * H;              // one timestep's gamma*log2e
-    static constexpr int LDS_FLOATS = 2 * SLAB + TABS + 2 * GROW;
+    static constexpr int RING = 3;                   // LDS ring buffers
+    static constexpr int LDS_FLOATS = RING * SLAB + TABS + 2 * GROW;
 };
 
 }  // namespace
@@ -74,43 +76,46 @@ __global__ __launch_bounds__(kThreads, 2) void card_sample_stream_kernel(const S
     static_assert(SLAB == NQ * kThreads * 4, "one slab = NQ b128 per thread");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const wbuf = lds;
-    float* const tabs = lds + 2 * SLAB;
+    float* const tabs = lds + G::RING * SLAB;
     float* const gbuf = tabs + G::TABS;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, n = lane & 15;
 
-    // prologue: tables, gamma row of the first step, slab 0
-    for (int i = tid * 4; i < G::TABS; i += kThreads * 4)
-        *reinterpret_cast<f32x4*>(tabs + i) = *reinterpret_cast<const f32x4*>(p.tabs + i);
-    for (int i = tid; i < G::GROW; i += kThreads) gbuf[i] = p.gtab[(long long)p.t_hi * G::GROW + i];
-#pragma unroll
-    for (int i = 0; i < NQ; ++i)
-        *reinterpret_cast<f32x4*>(wbuf + (i * kThreads + tid) * 4) = *reinterpret_cast<const f32x4*>(p.wimg + (i * kThreads + tid) * 4);
-    __syncthreads();
-
-    int cur = 0;      // LDS buffer holding the slab consumed next
-    int nxt = 1;      // index (in the per-timestep cycle) of the slab fetched next
-    int gcur = 0;     // gamma buffer of the current step
-    f32x4 stage[NQ];
     // slabs come through a buffer resource with a scalar offset: no per-lane 64-bit addresses to keep (or spill)
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wimg), 0, NS * SLAB * 4, 0x00020000);
     const int voff = tid * 16;
-    auto slab_fetch = [&]() {
-        const int so = nxt * (SLAB * 4);
+    f32x4 stage[NQ];          // the slab after the one being computed, on its way global -> registers -> ring
+    auto slab_fetch = [&](int slab) {
+        const int so = slab * (SLAB * 4);
 #pragma unroll
         for (int i = 0; i < NQ; ++i)
             stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, so + i * kThreads * 16, 0));
     };
-    auto slab_commit = [&]() {
-        float* dst = wbuf + (cur ^ 1) * SLAB + tid * 4;
+    auto stage_to_ring = [&](int buf) {
+        float* dst = wbuf + buf * SLAB + tid * 4;
 #pragma unroll
         for (int i = 0; i < NQ; ++i) *reinterpret_cast<f32x4*>(dst + i * kThreads * 4) = stage[i];
-        __syncthreads();
-        cur ^= 1;
-        nxt = nxt + 1 == NS ? 0 : nxt + 1;
     };
+
+    // prologue: tables, gamma row of the first step, slab 0 in ring buffer 0, slab 1 in flight
+    for (int i = tid * 4; i < G::TABS; i += kThreads * 4)
+        *reinterpret_cast<f32x4*>(tabs + i) = *reinterpret_cast<const f32x4*>(p.tabs + i);
+    for (int i = tid; i < G::GROW; i += kThreads) gbuf[i] = p.gtab[(long long)p.t_hi * G::GROW + i];
+    slab_fetch(0);
+    stage_to_ring(0);
+    slab_fetch(1);
+    __syncthreads();
+
+    int cur = 0;      // ring buffer holding the slab being computed
+    int nxt = 2;      // index (in the per-timestep cycle of NS slabs) of the slab fetched next
+    int gcur = 0;     // gamma buffer of the current step
+    // A fragments of the k-step about to run, always one k-step ahead of the MFMAs (also across slab, layer and
+    // timestep boundaries: the slab sequence is one endless stream)
+    f32x4 afrag[2][NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) afrag[0][q] = lds4(wbuf + lane * 4 + q * 256);
 
     const float* const bl = tabs + 4 * g;
     const float* const w4l = tabs + 3 * H + 4 * g;
@@ -182,30 +187,37 @@ __global__ __launch_bounds__(kThreads, 2) void card_sample_stream_kernel(const S
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[j] = lds4(bl + layer * H + 16 * j);
             };
-            // NKS k-steps of the current slab: acc[j] += A(slab)[j][ks] * b[ks]
-            auto compute = [&](auto nks_tag, auto off_tag, const auto& b) {
+            // One slab = NKS k-steps: acc[j] += A(slab)[j][ks] * b[OFF + ks].  Ring protocol (3 buffers, ONE barrier per
+            // slab, placed mid-slab where every wave has MFMA work on both sides of it):
+            //   top:   slab q+1 (fetched during slab q-1) registers -> buffer (cur+1)%3, last read during slab q-2, which
+            //          every wave had finished before it passed the barrier inside slab q-1; start fetching slab q+2
+            //   mid:   barrier: slab q+1 is now visible to all waves
+            //   end:   the last k-step prefetches the first A fragments of slab q+1 -- no bubble at the boundary
+            auto slab = [&](auto nks_tag, auto off_tag, const auto& b) {
                 constexpr int NKS = decltype(nks_tag)::value, OFF = decltype(off_tag)::value;
+                static_assert(NKS % 2 == 0, "fragment double buffer parity");
+                const int nb = cur == G::RING - 1 ? 0 : cur + 1;
                 const float* wl = wbuf + cur * SLAB + lane * 4;
-                // A fragments one k-step ahead; the compiler barriers keep the scheduler from hoisting a whole slab's
-                // LDS reads (128 VGPRs) above the MFMAs
-                f32x4 a[2][NQ];
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) a[0][q] = lds4(wl + q * 256);
+                const float* wn = wbuf + nb * SLAB + lane * 4;
+                stage_to_ring(nb);
+                slab_fetch(nxt);
+                nxt = nxt + 1 == NS ? 0 : nxt + 1;
 #pragma unroll
                 for (int s = 0; s < NKS; ++s) {
-                    asm volatile("" ::: "memory");
-                    if (s + 1 < NKS) {
+                    if (s == NKS / 2) __syncthreads();
+                    asm volatile("" ::: "memory");       // keep the scheduler from hoisting a whole slab's LDS reads
 #pragma unroll
-                        for (int q = 0; q < NQ; ++q) a[(s + 1) & 1][q] = lds4(wl + ((s + 1) * NQ + q) * 256);
-                    }
+                    for (int q = 0; q < NQ; ++q)
+                        afrag[(s + 1) & 1][q] = lds4(s + 1 < NKS ? wl + ((s + 1) * NQ + q) * 256 : wn + q * 256);
                     asm volatile("" ::: "memory");
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            acc[4 * q + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s & 1][q][e], b[OFF + s], acc[4 * q + e], 0, 0, 0);
+                            acc[4 * q + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[s & 1][q][e], b[OFF + s], acc[4 * q + e], 0, 0, 0);
                     }
                 }
+                cur = nb;
             };
             auto epilogue = [&](int layer) {
 #pragma unroll
@@ -221,9 +233,7 @@ __global__ __launch_bounds__(kThreads, 2) void card_sample_stream_kernel(const S
                 auto body = [&](auto self, auto S_tag) -> void {
                     constexpr int S = decltype(S_tag)::value;
                     if constexpr (S < NSH) {
-                        slab_fetch();
-                        compute(std::integral_constant<int, kSlabKs>{}, std::integral_constant<int, S * kSlabKs>{}, h);
-                        slab_commit();
+                        slab(std::integral_constant<int, kSlabKs>{}, std::integral_constant<int, S * kSlabKs>{}, h);
                         self(self, std::integral_constant<int, S + 1>{});
                     }
                 };
@@ -232,9 +242,9 @@ __global__ __launch_bounds__(kThreads, 2) void card_sample_stream_kernel(const S
             // ---- layer 1 (regression/model.py:48)
             if (g == 0) xin[0] = y;
             load_bias(0);
-            if constexpr (NS1 >= 1) { slab_fetch(); compute(std::integral_constant<int, (KS1 < 8 ? KS1 : 8)>{}, std::integral_constant<int, 0>{}, xin); slab_commit(); }
-            if constexpr (NS1 >= 2) { slab_fetch(); compute(std::integral_constant<int, (KS1 - 8 < 8 ? KS1 - 8 : 8)>{}, std::integral_constant<int, 8>{}, xin); slab_commit(); }
-            if constexpr (NS1 >= 3) { slab_fetch(); compute(std::integral_constant<int, (KS1 - 16 < 8 ? KS1 - 16 : 8)>{}, std::integral_constant<int, 16>{}, xin); slab_commit(); }
+            if constexpr (NS1 >= 1) slab(std::integral_constant<int, (KS1 < 8 ? KS1 : 8)>{}, std::integral_constant<int, 0>{}, xin);
+            if constexpr (NS1 >= 2) slab(std::integral_constant<int, (KS1 - 8 < 8 ? KS1 - 8 : 8)>{}, std::integral_constant<int, 8>{}, xin);
+            if constexpr (NS1 >= 3) slab(std::integral_constant<int, (KS1 - 16 < 8 ? KS1 - 16 : 8)>{}, std::integral_constant<int, 16>{}, xin);
             static_assert(NS1 <= 3, "layer 1 is built for at most 3 slabs (d_in <= 96)");
             epilogue(0);
             // ---- layers 2, 3 (:49-50)
@@ -332,7 +342,7 @@ typedef void (*stream_kernel_t)(const StreamParams);
 // smallest built layer-1 depth (in k-steps of 4 input columns) that holds d_in
 int stream_ks1_for(int d_in) {
     const int need = (d_in + 3) / 4;
-    for (int ks : {1, 2, 4, 8, 16, 24})
+    for (int ks : {2, 4, 8, 16, 24})
         if (need <= ks) return ks;
     return 0;
 }
@@ -340,7 +350,6 @@ int stream_ks1_for(int d_in) {
 stream_kernel_t stream_kernel_for(int H, int ks1) {
     if (H != 256) return nullptr;
     switch (ks1) {
-        case 1: return card_sample_stream_kernel<256, 1>;
         case 2: return card_sample_stream_kernel<256, 2>;
         case 4: return card_sample_stream_kernel<256, 4>;
         case 8: return card_sample_stream_kernel<256, 8>;
@@ -366,7 +375,7 @@ int stream_create(card_sampler* s, const card_model_desc* d, hipStream_t stream)
     const int ns1 = (ks1 + kSlabKs - 1) / kSlabKs, NSH = H / 32, SLAB = kSlabKs * (H / 16) * 64;
     s->k1 = ks1;
     s->kernel = reinterpret_cast<void (*)(const GuidedParams)>(kern);
-    s->lds_bytes = (size_t)(2 * SLAB + 4 * H + 4 + 2 * 3 * H) * sizeof(float);
+    s->lds_bytes = (size_t)(3 * SLAB + 4 * H + 4 + 2 * 3 * H) * sizeof(float);
     HIP_TRY(hipMalloc(&s->wpk, (size_t)(ns1 + 2 * NSH) * SLAB * sizeof(float)));
     HIP_TRY(hipMalloc(&s->w1s, (size_t)(4 * H + 4) * sizeof(float)));
     HIP_TRY(hipMalloc(&s->gtab, (size_t)d->n_embed * 3 * H * sizeof(float)));
