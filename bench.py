@@ -198,11 +198,11 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if persistent and os.path.exists(tpath):
-            tj = json.load(open(tpath))
             # measured for ONE full-size launch of the same shape (tools/profile_pmc.sh); valid when this run's
             # launches are that size too
-            if tj.get("x_dim") == x_dim and tj.get("T") == T and tj.get("rows_per_launch") == chunk and N >= chunk:
-                traffic = tj.get("hbm_bytes_per_launch")
+            for tj in json.load(open(tpath)).get("entries", []):
+                if (tj.get("x_dim"), tj.get("hidden"), tj.get("T"), tj.get("rows_per_launch")) == (x_dim, H, T, chunk) and N >= chunk:
+                    traffic = tj.get("hbm_bytes_per_launch")
         out = {
             "metric": "reverse-diffusion sample-steps/sec (p_sample_loop)",
             "value": value, "unit": "sample-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

@@ -39,7 +39,10 @@ typedef enum card_status {
 } card_status;
 
 typedef enum card_variant {
-    /* regression/model.py:21-51 ConditionalGuidedModel: cat(y_t, y_0_hat, x) -> 3 x (Linear, *gamma[t], softplus) -> Linear */
+    /* regression/model.py:21-51 ConditionalGuidedModel: cat(y_t, y_0_hat, x) -> 3 x (Linear, *gamma[t], softplus) -> Linear.
+       hidden = 128, y_dim = 1 (every reference config): persistent kernel, weights resident in LDS, no workspace;
+       hidden = 256, y_dim = 1, d_in <= 96: persistent kernel with weights streamed through LDS, no workspace;
+       any other hidden that is a multiple of 128, any y_dim: streaming-GEMM back end (needs a workspace). */
     CARD_VARIANT_GUIDED = 0,
     /* classification/model.py:22-94 ConditionalModel after the hoisted encoder: eval-BatchNorm after each
        ConditionalLinear and a Hadamard product with x_feat = norm(encoder_x(x)) after layer 1 */
@@ -78,7 +81,7 @@ typedef struct card_model_desc {
     int32_t variant;      /* card_variant */
     int32_t x_dim;        /* GUIDED: columns of x (used when cat_x);  BN_HADAMARD: must equal hidden */
     int32_t y_dim;        /* 1 for regression, number of classes for classification */
-    int32_t hidden;       /* H (128 for every reference regression model, regression/model.py:32-35) */
+    int32_t hidden;       /* H (128 for every reference regression model, regression/model.py:32-35); a multiple of 128 */
     int32_t n_embed;      /* rows of the gamma tables (= timesteps + 1, regression/model.py:24) */
     int32_t cat_x;        /* regression/model.py:25, GUIDED only */
     int32_t cat_y_pred;   /* regression/model.py:26; BN_HADAMARD: `guidance` (classification/model.py:31) */
@@ -136,19 +139,24 @@ typedef struct card_run_args {
                                (regression/card_regression.py:1027-1035) happens inside the kernel.  0 or 1: they
                                hold N rows.  y_init, noise and out are always per chain. */
     const int32_t* state_slot; /* device (T+1) ints, CARD_OUT_SELECT only */
-    void* workspace;        /* device scratch, 256-byte aligned, card_sampler_workspace_bytes(s, N) bytes
-                               (BN_HADAMARD: activations between the per-step GEMMs; GUIDED needs none: NULL) */
+    void* workspace;        /* device scratch, 256-byte aligned: activations between the per-step GEMMs of the GEMM back
+                               end (card_sampler_workspace_bytes reports a sufficient size; a smaller one makes the run
+                               walk the batch in chunks of as many chains as fit, at least n_z).  NULL for samplers on
+                               the persistent kernels (card_sampler_workspace_bytes reports 0). */
     uint64_t workspace_bytes;
 } card_run_args;
 
-/* Run timesteps t_hi ... t_lo of the reverse process for N independent chains in ONE persistent kernel.
+/* Run timesteps t_hi ... t_lo of the reverse process for N independent chains (persistent kernels: one launch per
+ * ~1M / ~262k chains for all timesteps; GEMM back end: five launches per timestep and chunk).
  * Replaces: p_sample_loop (regression/diffusion_utils.py:107-119, classification/diffusion_utils.py:119-144)
  * with y_init == NULL, t_hi = T-1, t_lo = 0;  p_sample (:57-90) with t_hi = t_lo = t >= 1;
  * p_sample_t_1to0 (:94-104) with t_hi = t_lo = 0. */
 CARD_API int card_sampler_run(const card_sampler* s, const card_run_args* args, void* stream);
 
-/* Scratch bytes card_sampler_run / card_eps_theta need for N rows (0 for GUIDED).  No reference counterpart:
- * the reference lets PyTorch allocate its activations; here the caller owns them so that a run never allocates. */
+/* Scratch bytes that suffice for card_sampler_run / card_eps_theta on N chains: 0 for samplers on the persistent
+ * kernels; on the GEMM back end the activations of min(N, about 4 GiB worth of) chains -- larger batches run in
+ * chunks, so the figure stops growing with N.  No reference counterpart: the reference lets PyTorch allocate its
+ * activations; here the caller owns them so that a run never allocates. */
 CARD_API int card_sampler_workspace_bytes(const card_sampler* s, int64_t N, uint64_t* bytes);
 
 /* eps_theta forward only: out (N, y_dim) = model(x, y_t, y_0_hat, t).
