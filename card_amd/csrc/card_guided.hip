@@ -331,18 +331,22 @@ __global__ __launch_bounds__(kThreads, 2) void card_sample_guided_kernel(const R
             }
             layer_hidden(w2l, bl + kH, gl + kH, hA, hB);
             layer_hidden(w3l, bl + 2 * kH, gl + 2 * kH, hB, hA);
-            float part = 0.0f;
+            // lin4: eps = W4 . h3 + b4 (regression/model.py:51) as four per-tile partial sums (two half-wave chains each)
+            // added in tile order -- the association the cooperative kernel below produces with one tile per wave, so
+            // both forms give the same bits and results do not depend on which one a batch size selects
+            float tp[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                float part = 0.0f;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 w = lds4(w4l + 32 * j + 8 * q);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) part = fmaf(hA[j][4 * q + e], w[e], part);
                 }
+                tp[j] = part + __shfl_xor(part, 32, 64);
             }
-            // lin4: eps = W4 . h3 + b4 (regression/model.py:51), two half-wave partial sums
-            const float eps = (part + __shfl_xor(part, 32, 64)) + b4;
+            const float eps = (((tp[0] + tp[1]) + tp[2]) + tp[3]) + b4;
 
             if (p.eps_only) {
                 if (valid && hh == 0) p.out[row] = eps;
@@ -368,6 +372,182 @@ __global__ __launch_bounds__(kThreads, 2) void card_sample_guided_kernel(const R
             __builtin_amdgcn_wave_barrier();
         }
         if (p.out_mode == CARD_OUT_LAST && !p.eps_only && valid && hh == 0) p.out[row] = y;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Small batches: the cooperative form.  Below ~49 000 chains the kernel above cannot give every SIMD two waves,
+// and a lone wave runs at half speed (nothing hides its LDS / MFMA-dependency stalls): the loop then takes the
+// same ~35 us per timestep whether 32 or 65 536 chains are in flight (regression/card_regression.py:1043 calls
+// p_sample_loop once per minibatch: 6 400 - 64 000 chains).  Here the FOUR waves of a workgroup (one per SIMD) share
+// one 32-chain tile: wave w owns output features [32w, 32w+32) of every layer, keeps ITS rows of W2 and W3 in
+// registers (2 x 64 VGPRs of A fragments: no weight traffic at all inside the loop) and the hoisted layer-1 tile in
+// 16 more; after each layer the waves exchange activations through a 17 KB LDS tile (chain-major, 4 x ds_write_b128
+// + barrier + 16 x ds_read_b128 per wave), and lin4 is a 4-way partial-sum exchange.  A timestep of a tile is then
+// ~130 dependent MFMAs per wave instead of 516: ~5 us instead of ~35.
+// ------------------------------------------------------------------------------------------------
+constexpr int kCoopWaves = 4;
+constexpr int kCoopThreads = kCoopWaves * 64;
+constexpr int kExLd = kH + 4;                          // exchange tile row stride (floats): conflict-free b128
+constexpr int kTabFloats = kOffW1 + kH - kOffB;        // b1|b2|b3|W4|b4|W1[:,0] as they sit in the packed image
+constexpr int kCoopLdsFloats = 2 * kTileM * kExLd + kCoopWaves * kTileM + 2 * kGammaRow + kTabFloats;
+
+__global__ __launch_bounds__(kCoopThreads) void card_sample_coop_kernel(const RunParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const ex = lds;                                         // 2 exchange tiles [32][132]
+    float* const red = ex + 2 * kTileM * kExLd;                    // [4][32] lin4 partial sums
+    float* const gsl = red + kCoopWaves * kTileM;                  // 2 gamma rows
+    float* const tab = gsl + 2 * kGammaRow;                        // small tables
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31, hh = lane >> 5;
+    for (int i = tid; i < kTabFloats; i += kCoopThreads) tab[i] = p.wpk[kOffB + i];
+
+    // this wave's A fragments of W2 and W3 (rows 32w .. 32w+31), same fragment order as the LDS image of the kernel above
+    float A2[64], A3[64];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p.wpk + kOffW2 + ((w * 16 + i) * 64 + lane) * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.wpk + kOffW3 + ((w * 16 + i) * 64 + lane) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { A2[4 * i + e] = a[e]; A3[4 * i + e] = b[e]; }
+    }
+    __syncthreads();
+    const float* const tb = tab + 4 * hh;                                        // bias rows: + layer * kH + 32w + 8q
+    const float* const w4l = tab + (kOffW4 - kOffB) + 32 * w + 4 * hh;
+    const float b4 = tab[kOffB4 - kOffB];
+    const float a10 = hh == 0 ? tab[(kOffW1 - kOffB) + 32 * w + m] : 0.0f;
+    float* const exw = ex + m * kExLd + 32 * w + 4 * hh;                         // where this lane publishes (+ 8q)
+    const float* const exr = ex + m * kExLd + 4 * hh;                            // where it reads (+ 32jj + 8q)
+
+    const long long n_rows = p.n_end - p.n_begin;
+    const long long n_tiles = (n_rows + kTileM - 1) / kTileM;
+    const int T = p.T;
+    const int draw0 = p.y_init ? (T - p.t_hi) : 0;
+    const int slot_base = draw0;
+    int gcur = 0;
+
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {       // same trip count for the 4 waves
+        const long long row = p.n_begin + tile * kTileM + m;
+        const bool valid = row < p.n_end;
+        const long long rc = valid ? row : p.n_end - 1;
+        const long long rr = p.n_z > 1 ? rc / p.n_z : rc;
+        const float mu = p.ytmean[rr];
+        const float y0h = p.y0hat[rr];
+        const unsigned long long elem = p.elem_offset + (unsigned long long)rc;
+        auto static_feature = [&](int k) -> float {
+            if (p.cat_y_pred && k == 1) return y0h;
+            const int xi = k - 1 - (p.cat_y_pred ? 1 : 0);
+            return (p.cat_x && xi < p.x_dim) ? p.x[rr * p.x_dim + xi] : 0.0f;
+        };
+        // hoisted layer 1 for this wave's 32 features: c1 = b1 + W1[:, 1:] . (y_0_hat, x), kept in registers
+        f32x16 c1;
+        load_bias(c1, tb, w);
+        for (int q = 0; q < p.nqs; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p.w1s + ((long long)(w * p.nqs + q) * 64 + lane) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], static_feature(1 + 8 * q + 2 * e + hh), c1, 0, 0, 0);
+        }
+        float zc[4];
+        uint32_t zblock = 0xFFFFFFFFu;
+        auto draw = [&](int d) -> float {
+            if (p.noise) return p.noise[(long long)(d - draw0) * p.N + rc];
+            const uint32_t blk = (uint32_t)d >> 2;
+            if (blk != zblock) {
+                philox_normal4(p.seed, elem, blk, zc);
+                zblock = blk;
+            }
+            return pick4(zc, d & 3);
+        };
+        auto store_state = [&](int s, float v) {
+            long long slot;
+            if (p.out_mode == CARD_OUT_ALL) slot = s - slot_base;
+            else if (p.out_mode == CARD_OUT_SELECT) slot = p.state_slot[s];
+            else return;
+            if (slot >= 0 && valid && hh == 0 && w == 0) p.out[slot * p.N + row] = v;
+        };
+        float y;
+        if (p.y_init) {
+            y = p.y_init[rc];
+        } else {
+            y = draw(0) + mu;                                 // diffusion_utils.py:109-110
+            store_state(0, y);
+        }
+        // gamma row of the first step (the previous tile's last reads of either buffer are behind its barriers)
+        for (int i = tid; i < kGammaRow; i += kCoopThreads) gsl[gcur * kGammaRow + i] = p.gtab[(long long)p.t_hi * kGammaRow + i];
+        __syncthreads();
+
+        // publish this wave's 32 x 32 block of activations / gather all 128 features of the tile's chains
+        auto publish = [&](const f32x16& a, int buf) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = {a[4 * q + 0], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+                *reinterpret_cast<f32x4*>(exw + buf * kTileM * kExLd + 8 * q) = v;
+            }
+        };
+        auto hidden = [&](const float (&A)[64], int buf, int layer, const float* gl) -> f32x16 {
+            f32x16 acc;
+            load_bias(acc, tb + layer * kH, w);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {                    // i = 4jj + q: features 32jj + 8q + 4hh .. +3
+                const f32x4 h = lds4(exr + buf * kTileM * kExLd + 32 * (i >> 2) + 8 * (i & 3));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * i + e], h[e], acc, 0, 0, 0);
+            }
+            epilogue_tile(acc, gl + layer * kH, w);
+            return acc;
+        };
+
+        for (int t = p.t_hi; t >= p.t_lo; --t) {
+            const bool more = t > p.t_lo;
+            f32x4 gn = {0.f, 0.f, 0.f, 0.f};
+            if (more && tid < kGammaRow / 4) gn = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(t - 1) * kGammaRow + tid * 4);
+            const float z = t >= 1 && !p.eps_only ? draw(T - t) : 0.0f;
+            const float* const gl = gsl + gcur * kGammaRow + 4 * hh;
+
+            f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a10, hh == 0 ? y : 0.0f, c1, 0, 0, 0);
+            epilogue_tile(acc, gl, w);
+            publish(acc, 0);
+            __syncthreads();
+            acc = hidden(A2, 0, 1, gl);
+            publish(acc, 1);
+            __syncthreads();
+            acc = hidden(A3, 1, 2, gl);
+            // next step's gamma row: written between two barriers of this step, read after the next one
+            if (more && tid < kGammaRow / 4) *reinterpret_cast<f32x4*>(gsl + (gcur ^ 1) * kGammaRow + tid * 4) = gn;
+            // lin4: this wave's partial over its 32 features, then the four waves' partials in a fixed order
+            float part = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 wv = lds4(w4l + 8 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part = fmaf(acc[4 * q + e], wv[e], part);
+            }
+            part += __shfl_xor(part, 32, 64);
+            if (hh == 0) red[w * kTileM + m] = part;
+            __syncthreads();
+            const float eps = (((red[m] + red[kTileM + m]) + red[2 * kTileM + m]) + red[3 * kTileM + m]) + b4;
+            gcur ^= more ? 1 : 0;
+
+            if (p.eps_only) {
+                if (valid && hh == 0 && w == 0) p.out[row] = eps;
+                break;
+            }
+            const float* c = p.coef + (long long)t * CARD_COEF_COLS;
+            const float y0r = c[CARD_COEF_INV_SQRT_AB] * ((y - c[CARD_COEF_ONE_M_SQRT_AB] * mu) - eps * c[CARD_COEF_SOMAB]);
+            if (t >= 1) {
+                const float yh = (c[CARD_COEF_G0] * y0r + c[CARD_COEF_G1] * y) + c[CARD_COEF_G2] * mu;
+                y = yh + c[CARD_COEF_SIGMA] * z;
+            } else {
+                y = y0r;
+            }
+            store_state(T - t, y);
+        }
+        if (p.out_mode == CARD_OUT_LAST && !p.eps_only && valid && hh == 0 && w == 0) p.out[row] = y;
+        __syncthreads();                                      // the next tile rewrites the gamma buffer and red[]
     }
 }
 
@@ -465,6 +645,15 @@ int guided_create(card_sampler* s, const card_model_desc* d, hipStream_t stream)
     if (hoist) HIP_TRY(hipMalloc(&s->ws, (size_t)s->num_cu * kWaves * kSlotFloats * sizeof(float)));
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
     if (hoist) HIP_TRY(hipFuncSetAttribute((const void*)guided_kernel_for(k1, 2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
+    // cooperative small-batch form (needs the hoisted image layout); CARD_AMD_COOP=0 switches it off for A/B runs
+    s->coop_blocks = 0;
+    const char* cv = getenv("CARD_AMD_COOP");
+    if (hoist && !(cv && cv[0] == '0')) {
+        int nb = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)card_sample_coop_kernel, kCoopThreads,
+                                                             (size_t)kCoopLdsFloats * sizeof(float)));
+        s->coop_blocks = nb < 1 ? 1 : (nb > 2 ? 2 : nb);
+    }
     pack_hidden_kernel<<<kH * kH / 256, 256, 0, stream>>>(d->W[1], kLn2, s->wpk + kOffW2);
     pack_hidden_kernel<<<kH * kH / 256, 256, 0, stream>>>(d->W[2], kLn2, s->wpk + kOffW3);
     if (hoist) {
@@ -499,6 +688,19 @@ int guided_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     p.w1s = s->w1s; p.ws = s->ws; p.nqs = s->nqs;
     // Split very large N into launches of whole waves-worth of tiles so that one launch stays well under
     // a second and every wave gets the same number of tiles (no intra-launch tail except in the last one).
+    // Small batches (the reference's per-minibatch calls): up to 2048 tiles the persistent kernel takes ~35 us per
+    // timestep whatever the batch (waves alone on their SIMD); the cooperative form takes ~5.6 us per round of num_cu
+    // tiles (measured, tools/bench_small.py), so it wins up to five rounds.
+    const long long tiles_total = (p.N + kTileM - 1) / kTileM;
+    if (s->coop_blocks > 0 && tiles_total <= 5LL * s->num_cu * s->coop_blocks) {
+        p.n_begin = 0;
+        p.n_end = p.N;
+        const long long cap = (long long)s->num_cu * s->coop_blocks;
+        const long long grid = tiles_total < cap ? tiles_total : cap;
+        card_sample_coop_kernel<<<dim3((unsigned)grid), dim3(kCoopThreads), (size_t)kCoopLdsFloats * sizeof(float), stream>>>(p);
+        HIP_TRY(hipGetLastError());
+        return CARD_OK;
+    }
     const long long waves = (long long)s->num_cu * kWaves;
     const long long tiles_per_wave = 16;
     const long long chunk = waves * tiles_per_wave * kTileM;

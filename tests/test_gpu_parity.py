@@ -55,6 +55,14 @@ def _need_gpu():
     assert torch.cuda.is_available(), "these tests need the MI355X"
 
 
+@pytest.fixture(params=["coop", "persistent"], autouse=True)
+def small_batch_kernel(request, monkeypatch):
+    """Every test runs twice: with the cooperative small-batch kernel (the default below ~24 000 chains) and with it
+    switched off (CARD_AMD_COOP=0, read when a sampler is created), so the fixtures pin both kernels."""
+    monkeypatch.setenv("CARD_AMD_COOP", "1" if request.param == "coop" else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("name", SUPPORTED_REG)
 def test_free_running_loop_matches_reference(name):
     g = load_golden(name)
