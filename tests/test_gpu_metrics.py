@@ -70,3 +70,50 @@ def test_metric_sums_over_states_and_finalize():
         assert abs(float(fin["picp"][k]) - inr.mean()) < 1e-12
         assert abs(float(fin["qice"][k]) - qice) < 1e-12
         assert abs(float(fin["nll"][k]) - nll.mean()) < 1e-4
+
+
+def test_end_to_end_metrics_within_seed_to_seed_variance():
+    """north_star, end-to-end level: with in-kernel RNG, RMSE / NLL / PICP / QICE of the HIP path (sampling + on-device
+    metrics) match the reference pipeline (oracle sampling driven by torch.randn + the numpy restatement of the
+    reference's metric helpers) within the spread the reference shows between two seeds of its own."""
+    from card_amd import _lib
+    from card_amd.sampler import Sampler, make_coef_table
+    from oracle import card_oracle as orc
+    from tests.helpers import load_golden
+    g = load_golden("reg_boston_T50")                 # trained fixture model, T = 50
+    T, n_z, n_bins = g["T"], 400, 10
+    reps = 12                                         # 40 fixture rows x 12 perturbed copies = 480 test rows
+    gen = torch.Generator().manual_seed(77)
+    x = g["x"].repeat(reps, 1) + 0.05 * torch.randn(40 * reps, g["x"].shape[1], generator=gen)
+    y0 = g["y0hat"].repeat(reps, 1) + 0.05 * torch.randn(40 * reps, 1, generator=gen)
+    rows = x.shape[0]
+    tile = lambda t: t.repeat_interleave(n_z, 0)
+
+    def reference_run(seed):
+        torch.manual_seed(seed)
+        y = orc.p_sample_loop(g["weights"], tile(x), tile(y0), tile(y0), T, g["alphas"], g["omabs"],
+                              torch.randn(T, rows * n_z, 1), only_last_sample=True)
+        return y.reshape(rows, n_z, 1).numpy()
+
+    ref_a, ref_b = reference_run(1), reference_run(2)
+    # targets drawn from the model's own predictive distribution (a third reference run), so the metrics are
+    # in their calibrated regime (PICP ~ 0.95, QICE ~ 0)
+    y_true = torch.from_numpy(reference_run(3)[:, 0])
+
+    def ref_summary(genr):
+        se, nll, member, inr = reference_metrics(genr, y_true.numpy(), n_bins, (2.5, 97.5), (0.0, 100.0), 1.0, 0.0, None)
+        counts = np.array([(member == v).sum() for v in np.arange(n_bins + 2)])
+        counts[1] += counts[0]; counts[-2] += counts[-1]
+        return {"rmse": np.sqrt(se.mean()), "nll": nll.mean(), "picp": inr.mean(),
+                "qice": np.absolute(np.ones(n_bins) / n_bins - counts[1:-1] / rows).mean()}
+
+    a, b = ref_summary(ref_a), ref_summary(ref_b)
+    s = Sampler.from_state_dict(g["sd"], device=DEV)
+    coef = make_coef_table(g["alphas"], g["omabs"]).to(DEV)
+    y = s.run(x.to(DEV), y0.to(DEV), y0.to(DEV), coef, T, seed=2024, n_z=n_z)
+    fin = metrics.finalize(metrics.regression_metric_sums(y.reshape(rows, n_z, 1), y_true.to(DEV), n_bins=n_bins), n_bins)
+    floor = {"rmse": 0.02, "nll": 0.03, "picp": 0.02, "qice": 0.01}     # sampling-error floor at 480 rows x 400 samples
+    for k in ("rmse", "nll", "picp", "qice"):
+        hip, spread = float(fin[k][0]), abs(a[k] - b[k])
+        print(f"{k}: hip {hip:.4f}  reference seeds {a[k]:.4f} / {b[k]:.4f}")
+        assert abs(hip - a[k]) <= max(3 * spread, floor[k]) and abs(hip - b[k]) <= max(3 * spread, floor[k]), k
