@@ -95,19 +95,25 @@ __device__ __forceinline__ void load_bias(f32x16& acc, const float* bl, int j) {
 // accumulators).  wl: packed weights, bl: bias, gl: this step's gamma*log2e (all LDS, pre-offset by lane).
 __device__ __forceinline__ void layer_hidden(const float* wl, const float* bl, const float* gl, const f32x16 (&hin)[4],
                                              f32x16 (&hout)[4]) {
+    // A fragments run one group (4 MFMAs = 256 cycles) ahead of their use, across output tiles too; the compiler
+    // barriers pin that order (left alone, the scheduler sinks every ds_read next to its first MFMA and each group
+    // then waits out the full LDS latency)
+    f32x4 a = lds4(wl);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         f32x16 acc;
         load_bias(acc, bl, j);
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
+        for (int i = 0; i < 16; ++i) {                  // i = 4jj + q
+            const int g = j * 16 + i;
+            f32x4 an = a;
+            asm volatile("" ::: "memory");
+            if (g + 1 < 64) an = lds4(wl + (g + 1) * 256);
+            asm volatile("" ::: "memory");
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 a = lds4(wl + (((j * 4 + jj) * 4 + q) * 64) * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], hin[jj][4 * q + e], acc, 0, 0, 0);
-            }
+            for (int e = 0; e < 4; ++e)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], hin[i >> 2][4 * (i & 3) + e], acc, 0, 0, 0);
+            a = an;
         }
         epilogue_tile(acc, gl, j);
         hout[j] = acc;
@@ -200,7 +206,9 @@ __global__ __launch_bounds__(kThreads, 2) void card_sample_guided_kernel(const R
     const int draw0 = p.y_init ? (T - p.t_hi) : 0;       // first draw this call consumes
     const int slot_base = p.y_init ? (T - p.t_hi) : 0;   // CARD_OUT_ALL: first state this call produces
 
-    for (long long tile = (long long)blockIdx.x * kWaves + wave; tile < n_tiles; tile += stride) {
+    // tile -> (workgroup, wave): consecutive tiles go to different workgroups first, so a batch with fewer tiles than
+    // wave slots spreads over all CUs (one wave per SIMD up to 4 x grid tiles) instead of filling a few CUs
+    for (long long tile = (long long)wave * gridDim.x + blockIdx.x; tile < n_tiles; tile += stride) {
         const long long row = p.n_begin + tile * kTileM + m;
         const bool valid = row < p.n_end;
         const long long rc = valid ? row : p.n_end - 1;
@@ -377,15 +385,14 @@ __global__ __launch_bounds__(kThreads, 2) void card_sample_guided_kernel(const R
 
 
 // ------------------------------------------------------------------------------------------------
-// Small batches: the cooperative form.  Below ~49 000 chains the kernel above cannot give every SIMD two waves,
-// and a lone wave runs at half speed (nothing hides its LDS / MFMA-dependency stalls): the loop then takes the
-// same ~35 us per timestep whether 32 or 65 536 chains are in flight (regression/card_regression.py:1043 calls
+// Small batches: the cooperative form.  A timestep of a tile is a dependent chain of ~520 MFMAs for the wave that
+// owns it (~19.5 us with a SIMD to itself), however few tiles there are (regression/card_regression.py:1043 calls
 // p_sample_loop once per minibatch: 6 400 - 64 000 chains).  Here the FOUR waves of a workgroup (one per SIMD) share
 // one 32-chain tile: wave w owns output features [32w, 32w+32) of every layer, keeps ITS rows of W2 and W3 in
 // registers (2 x 64 VGPRs of A fragments: no weight traffic at all inside the loop) and the hoisted layer-1 tile in
 // 16 more; after each layer the waves exchange activations through a 17 KB LDS tile (chain-major, 4 x ds_write_b128
 // + barrier + 16 x ds_read_b128 per wave), and lin4 is a 4-way partial-sum exchange.  A timestep of a tile is then
-// ~130 dependent MFMAs per wave instead of 516: ~5 us instead of ~35.
+// ~130 dependent MFMAs per wave instead of 516: ~5.6 us.
 // ------------------------------------------------------------------------------------------------
 constexpr int kCoopWaves = 4;
 constexpr int kCoopThreads = kCoopWaves * 64;
@@ -688,11 +695,14 @@ int guided_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     p.w1s = s->w1s; p.ws = s->ws; p.nqs = s->nqs;
     // Split very large N into launches of whole waves-worth of tiles so that one launch stays well under
     // a second and every wave gets the same number of tiles (no intra-launch tail except in the last one).
-    // Small batches (the reference's per-minibatch calls): up to 2048 tiles the persistent kernel takes ~35 us per
-    // timestep whatever the batch (waves alone on their SIMD); the cooperative form takes ~5.6 us per round of num_cu
-    // tiles (measured, tools/bench_small.py), so it wins up to five rounds.
+    // Small batches (the reference's per-minibatch calls).  Measured per 1000 timesteps (tools/bench_small.py): the
+    // cooperative form takes 5.6 ms per round of num_cu tiles; the persistent kernel 19.5 ms while every tile has a
+    // SIMD to itself (<= 4 x num_cu tiles) and 35 ms up to 8 x num_cu tiles.  So: cooperative up to three rounds,
+    // persistent up to 4 x num_cu tiles, cooperative again for a fifth round, persistent beyond.
     const long long tiles_total = (p.N + kTileM - 1) / kTileM;
-    if (s->coop_blocks > 0 && tiles_total <= 5LL * s->num_cu * s->coop_blocks) {
+    const long long per_round = (long long)s->num_cu * (s->coop_blocks > 0 ? s->coop_blocks : 1);
+    const long long rounds = (tiles_total + per_round - 1) / per_round;
+    if (s->coop_blocks > 0 && (rounds <= 3 || (tiles_total > 4LL * s->num_cu && rounds <= 5))) {
         p.n_begin = 0;
         p.n_end = p.N;
         const long long cap = (long long)s->num_cu * s->coop_blocks;
@@ -708,8 +718,7 @@ int guided_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
         p.n_begin = b;
         p.n_end = b + chunk < p.N ? b + chunk : p.N;
         const long long tiles = (p.n_end - p.n_begin + kTileM - 1) / kTileM;
-        long long grid = (tiles + kWaves - 1) / kWaves;
-        if (grid > s->num_cu) grid = s->num_cu;
+        const long long grid = tiles < s->num_cu ? tiles : s->num_cu;
         // in-kernel row tiling with n_z >= 32: the hoisted layer-1 tile has two distinct columns -> LDS-resident form
         sample_kernel_t kern = (s->hoist && r.n_z >= 32) ? guided_kernel_for(s->k1, 2) : s->kernel;
         kern<<<dim3((unsigned)grid), dim3(kThreads), s->lds_bytes, stream>>>(p);
