@@ -75,12 +75,28 @@ typedef GuidedParams RunParams;
 
 // gamma multiply + softplus of one 32-feature x 32-chain accumulator tile, in place
 __device__ __forceinline__ void epilogue_tile(f32x16& acc, const float* gl, int j) {
+    // staged over the tile's 16 registers (all multiplies, all exp2, all +1, all log2, all selects): the transcendental
+    // pipe is quarter rate with a long result latency, and a per-element chain mul -> exp -> add -> log -> med3 (what
+    // the scheduler emits for the obvious loop) stalls on every link
+    float xs[16], e[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const f32x4 g = lds4(gl + 32 * j + 8 * q);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[4 * q + e] = softplus_l2(acc[4 * q + e] * g[e]);
+        for (int k = 0; k < 4; ++k) xs[4 * q + k] = acc[4 * q + k] * g[k];
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(xs[r]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) e[r] = 1.0f + e[r];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_logf(e[r]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = __builtin_amdgcn_fmed3f(e[r], xs[r], kSpThresh);
 }
 
 __device__ __forceinline__ void load_bias(f32x16& acc, const float* bl, int j) {

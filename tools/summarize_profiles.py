@@ -4,6 +4,8 @@ profiles/ (round tag argv[1])."""
 import collections, csv, glob, json, os, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 os.makedirs("profiles", exist_ok=True)
+if os.path.exists("gpurun_out/ubench.txt"):
+    open(f"profiles/{tag}_ubench.txt", "w").write(open("gpurun_out/ubench.txt").read())
 
 for name in ("bench", "cifar", "stream"):
     for p in glob.glob(f"gpurun_out/prof_{name}/*/*kernel_stats.csv"):
