@@ -73,12 +73,24 @@ struct GuidedParams {
 namespace {
 typedef GuidedParams RunParams;
 
+// Wave priorities of the two kinds of phase.  With equal priorities the two waves of a SIMD are issued alternately and
+// an epilogue's VALU ops get threaded between the partner's MFMAs, each MFMA <-> VALU switch costing ~14 cycles
+// (tools/ubench/interleave); with different priorities one wave runs its block through (measured +2 %).
+#ifndef CARD_PRIO_VALU
+#define CARD_PRIO_VALU 3
+#endif
+#ifndef CARD_PRIO_MFMA
+#define CARD_PRIO_MFMA 0
+#endif
+constexpr int kPrioValu = CARD_PRIO_VALU, kPrioMfma = CARD_PRIO_MFMA;
+
 // gamma multiply + softplus of one 32-feature x 32-chain accumulator tile, in place
 __device__ __forceinline__ void epilogue_tile(f32x16& acc, const float* gl, int j) {
     // staged over the tile's 16 registers (all multiplies, all exp2, all +1, all log2, all selects): the transcendental
     // pipe is quarter rate with a long result latency, and a per-element chain mul -> exp -> add -> log -> med3 (what
     // the scheduler emits for the obvious loop) stalls on every link
     float xs[16], e[16];
+    __builtin_amdgcn_s_setprio(kPrioValu);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const f32x4 g = lds4(gl + 32 * j + 8 * q);
@@ -97,6 +109,7 @@ __device__ __forceinline__ void epilogue_tile(f32x16& acc, const float* gl, int 
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = __builtin_amdgcn_fmed3f(e[r], xs[r], kSpThresh);
+    __builtin_amdgcn_s_setprio(kPrioMfma);
 }
 
 __device__ __forceinline__ void load_bias(f32x16& acc, const float* bl, int j) {
