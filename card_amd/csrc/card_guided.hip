@@ -429,7 +429,7 @@ constexpr int kExLd = kH + 4;                          // exchange tile row stri
 constexpr int kTabFloats = kOffW1 + kH - kOffB;        // b1|b2|b3|W4|b4|W1[:,0] as they sit in the packed image
 constexpr int kCoopLdsFloats = 2 * kTileM * kExLd + kCoopWaves * kTileM + 2 * kGammaRow + kTabFloats;
 
-__global__ __launch_bounds__(kCoopThreads) void card_sample_coop_kernel(const RunParams p) {
+__global__ __launch_bounds__(kCoopThreads, 2) void card_sample_coop_kernel(const RunParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const ex = lds;                                         // 2 exchange tiles [32][132]
     float* const red = ex + 2 * kTileM * kExLd;                    // [4][32] lin4 partial sums
@@ -689,6 +689,7 @@ int guided_create(card_sampler* s, const card_model_desc* d, hipStream_t stream)
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)card_sample_coop_kernel, kCoopThreads,
                                                              (size_t)kCoopLdsFloats * sizeof(float)));
         s->coop_blocks = nb < 1 ? 1 : (nb > 2 ? 2 : nb);
+        s->coop_force = (cv && cv[0] == '2') ? 1 : 0;     // CARD_AMD_COOP=2: cooperative kernel for every batch size (A/B)
     }
     pack_hidden_kernel<<<kH * kH / 256, 256, 0, stream>>>(d->W[1], kLn2, s->wpk + kOffW2);
     pack_hidden_kernel<<<kH * kH / 256, 256, 0, stream>>>(d->W[2], kLn2, s->wpk + kOffW3);
@@ -725,13 +726,11 @@ int guided_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     // Split very large N into launches of whole waves-worth of tiles so that one launch stays well under
     // a second and every wave gets the same number of tiles (no intra-launch tail except in the last one).
     // Small batches (the reference's per-minibatch calls).  Measured per 1000 timesteps (tools/bench_small.py): the
-    // cooperative form takes 5.6 ms per round of num_cu tiles; the persistent kernel 19.5 ms while every tile has a
-    // SIMD to itself (<= 4 x num_cu tiles) and 35 ms up to 8 x num_cu tiles.  So: cooperative up to three rounds,
-    // persistent up to 4 x num_cu tiles, cooperative again for a fifth round, persistent beyond.
+    // cooperative form takes 5.4 ms for up to num_cu tiles and 9.1 ms per round of 2 x num_cu tiles (two workgroups per
+    // CU); the persistent kernel 18.1 ms while every tile has a SIMD to itself (<= 4 x num_cu tiles), 33.8 ms up to
+    // 8 x num_cu tiles.  The cooperative form is ahead up to 3.5 rounds = 7 x num_cu tiles (57 344 chains on 256 CUs).
     const long long tiles_total = (p.N + kTileM - 1) / kTileM;
-    const long long per_round = (long long)s->num_cu * (s->coop_blocks > 0 ? s->coop_blocks : 1);
-    const long long rounds = (tiles_total + per_round - 1) / per_round;
-    if (s->coop_blocks > 0 && (rounds <= 3 || (tiles_total > 4LL * s->num_cu && rounds <= 5))) {
+    if (s->coop_blocks > 0 && (s->coop_force || tiles_total <= 7LL * s->num_cu)) {
         p.n_begin = 0;
         p.n_end = p.N;
         const long long cap = (long long)s->num_cu * s->coop_blocks;

@@ -28,6 +28,7 @@ struct card_sampler {
     int backend;   // 0: persistent kernel (card_guided.hip), 1: streaming GEMMs (card_wide.hip), 2: persistent kernel with streamed weights (card_stream.hip)
     // ---- CARD_VARIANT_GUIDED (card_guided.hip)
     int k1, hoist, nqs;
+    int coop_force;
     int coop_blocks;   // > 0: workgroups per CU of the cooperative small-batch kernel (0: not available)
     float* wpk;    // packed LDS image
     float* gtab;   // (n_embed, 3, H) gamma * log2e [* bn_scale]
