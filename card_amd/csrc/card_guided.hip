@@ -1,4 +1,5 @@
-// card_guided.hip - the persistent sampler kernel for CARD_VARIANT_GUIDED (regression ConditionalGuidedModel).
+// card_guided.hip - the sampler kernels for CARD_VARIANT_GUIDED at hidden 128 (regression ConditionalGuidedModel):
+// the persistent kernel described here and, for small batches, the cooperative form further down.
 //
 // One launch runs all T timesteps of p_sample_loop (reference: regression/diffusion_utils.py:107-119) for up
 // to 1 048 576 independent (row, z) chains:
@@ -9,14 +10,16 @@
 //   * W2, W3, biases and W4 live in LDS for the whole kernel in "fragment order" (one ds_read_b128 per
 //     lane yields the A operands of four consecutive MFMAs, conflict-free); per-step gamma rows are staged
 //     through a small wave-private LDS slab, prefetched one step ahead
-//   * layer 1: the step-invariant part b1 + W1[:,1:].(y_0_hat, x) is computed once per tile into a per-wave
-//     16 KB scratch slot (re-read from L2 each step) and one K=2 MFMA per output tile adds W1[:,0]*y_t
-//     (HOIST, any d_in); or, without scratch, W1 stays in LDS and layer 1 runs on MFMA every step (d_in <= 32)
+//   * layer 1: the step-invariant part b1 + W1[:,1:].(y_0_hat, x) is computed once per tile and one K=2 MFMA per
+//     output tile adds W1[:,0]*y_t each step (HOIST, any d_in): kept as two columns in LDS when rows are tiled
+//     in-kernel with n_z >= 32, else in a per-wave 16 KB scratch slot re-read from L2; or, un-hoisted, W1 stays in
+//     LDS and layer 1 runs on MFMA every step (d_in <= 32, CARD_AMD_HOIST=0)
 //   * epilogue per element: xs = acc * (gamma*log2e); softplus/ln2 = xs > 20*log2e ? xs : log2(1 + exp2(xs))
 //     (ln2 is folded into the next layer's weights), i.e. F.softplus(beta=1, threshold=20)
-//   * measured on gfx950: v_mfma_f32_32x32x2_f32 does NOT overlap with VALU work of either wave of a SIMD
-//     (tools/ubench), so MFMA and epilogue are issued as large blocks and the kernel's ceiling is
-//     MFMA time / (MFMA time + VALU time)
+//   * measured on gfx950: v_mfma_f32_32x32x2_f32 barely overlaps with VALU work of either wave of a SIMD
+//     (tools/ubench), so MFMA and epilogue are issued as large blocks (A fragments pinned one group ahead, the
+//     epilogue staged over a tile and run at raised wave priority) and the kernel's ceiling is about
+//     MFMA time / (MFMA time + VALU time) = 80 %
 //   * noise: injected (validation) or Philox4x32-10 + Box-Muller keyed by (seed, element, draw)
 #include "card_internal.h"
 
