@@ -301,3 +301,16 @@ def test_in_kernel_row_tiling_equals_host_tiling():
         assert norm_rel_err(a.cpu(), want) <= TOL
     with pytest.raises(_lib.CardError):
         s.run(cuda(x), cuda(y0), cuda(y0[:-1]), coef, T, n_z=n_z)
+
+
+def test_cooperative_kernel_many_tiles_per_workgroup(monkeypatch):
+    """40 000 chains = 1250 tiles on at most 512 cooperative workgroups (each walks two or three tiles) against the
+    persistent kernel on the same batch: the two kernels are bit-identical by construction."""
+    g = load_golden("reg_boston_T50")
+    reps = 1000
+    outs = []
+    for mode in ("2", "0"):                               # cooperative forced / switched off
+        monkeypatch.setenv("CARD_AMD_COOP", mode)
+        s = Sampler.from_state_dict(g["sd"], cat_x=g["cat_x"], cat_y_pred=g["cat_y_pred"], device=DEV)
+        outs.append(_raw_run(s, g, N_rep=reps, seed=17, out_mode=_lib.OUT_SELECT, states=[0, 10, g["T"]]))
+    assert outs[0].shape[1] == 40 * reps and torch.equal(outs[0], outs[1])

@@ -101,3 +101,21 @@ def test_stream_kernel_row_tiling_and_many_groups():
     err = norm_rel_err(a.cpu(), c.cpu())
     print(f"stream vs GEMM back end, 40k chains: {err:.3e}")
     assert err <= TOL
+
+
+def test_stream_kernel_several_launches():
+    """300 000 chains = two launches of the streamed kernel (262 144 chains each at most): agree with the GEMM back end
+    and are finite; the second launch's chains use their own rows / RNG elements (n_begin offset)."""
+    T, rows, n_z = 3, 3000, 100
+    sd, x, y0, mu, _, alphas, omabs = _case(13, T, rows, 61)
+    s = Sampler.from_state_dict(sd, device=DEV)
+    coef = cuda(make_coef_table(alphas, omabs))
+    a = s.run(cuda(x), cuda(y0), cuda(mu), coef, T, seed=4, n_z=n_z)
+    os.environ["CARD_AMD_STREAM"] = "0"
+    try:
+        sg = Sampler.from_state_dict(sd, device=DEV)
+    finally:
+        del os.environ["CARD_AMD_STREAM"]
+    b = sg.run(cuda(x), cuda(y0), cuda(mu), coef, T, seed=4, n_z=n_z)
+    assert a.shape == (rows * n_z, 1) and torch.isfinite(a).all()
+    assert norm_rel_err(a.cpu(), b.cpu()) <= TOL
