@@ -116,9 +116,10 @@ extern "C" CARD_API int card_sampler_create(const card_model_desc* d, void* stre
     }
     // the persistent kernel is built for the reference's regression network (H = 128, y_dim = 1); every other
     // shape (classification heads, wider or multi-output regression nets) streams through the GEMM back end
-    s->backend = (d->variant == CARD_VARIANT_GUIDED && d->hidden == 128 && d->y_dim == 1) ? 0 : (stream_supports(d, s->d_in) ? 2 : 1);
+    s->backend = (d->variant == CARD_VARIANT_GUIDED && d->hidden == 128 && d->y_dim == 1) ? 0 : (stream_supports(d, s->d_in) ? 2 : (clscoop_supports(d) ? 3 : 1));
     const int rc = s->backend == 0 ? guided_create(s, d, (hipStream_t)stream_)
-                 : s->backend == 2 ? stream_create(s, d, (hipStream_t)stream_) : wide_create(s, d, (hipStream_t)stream_);
+                 : s->backend == 2 ? stream_create(s, d, (hipStream_t)stream_)
+                 : s->backend == 3 ? clscoop_create(s, d, (hipStream_t)stream_) : wide_create(s, d, (hipStream_t)stream_);
     if (rc != CARD_OK) {
         card_sampler_destroy(s);
         return rc;
@@ -131,6 +132,7 @@ extern "C" CARD_API void card_sampler_destroy(card_sampler* s) {
     if (!s) return;
     if (s->backend == 0) guided_destroy(s);
     else if (s->backend == 2) stream_destroy(s);
+    else if (s->backend == 3) clscoop_destroy(s);
     else wide_destroy(s);
     delete s;
 }
@@ -170,7 +172,8 @@ extern "C" CARD_API int card_sampler_run(const card_sampler* s, const card_run_a
     r.T = a->T; r.t_hi = a->t_hi; r.t_lo = a->t_lo; r.out_mode = a->out_mode; r.eps_only = 0;
     r.n_z = a->n_z > 1 ? a->n_z : 1;
     return s->backend == 0 ? guided_run(s, r, (hipStream_t)stream)
-         : s->backend == 2 ? stream_run(s, r, (hipStream_t)stream) : wide_run(s, r, (hipStream_t)stream);
+         : s->backend == 2 ? stream_run(s, r, (hipStream_t)stream)
+         : s->backend == 3 ? clscoop_run(s, r, (hipStream_t)stream) : wide_run(s, r, (hipStream_t)stream);
 }
 
 extern "C" CARD_API int card_eps_theta(const card_sampler* s, const float* x, const float* y_t, const float* y_0_hat,
@@ -188,7 +191,8 @@ extern "C" CARD_API int card_eps_theta(const card_sampler* s, const float* x, co
     r.workspace = workspace; r.workspace_bytes = workspace_bytes;
     r.T = t + 1; r.t_hi = t; r.t_lo = t; r.out_mode = CARD_OUT_LAST; r.eps_only = 1; r.n_z = 1;
     return s->backend == 0 ? guided_run(s, r, (hipStream_t)stream)
-         : s->backend == 2 ? stream_run(s, r, (hipStream_t)stream) : wide_run(s, r, (hipStream_t)stream);
+         : s->backend == 2 ? stream_run(s, r, (hipStream_t)stream)
+         : s->backend == 3 ? clscoop_run(s, r, (hipStream_t)stream) : wide_run(s, r, (hipStream_t)stream);
 }
 
 extern "C" CARD_API int card_q_sample(const float* y, const float* y_0_hat, const float* sab, const float* somab,

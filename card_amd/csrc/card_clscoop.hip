@@ -1,0 +1,405 @@
+// card_clscoop.hip - cooperative persistent kernel for the classification ConditionalModel at feature width 128
+// (classification/model.py:79-94 after the hoisted encoder; classification/configs/mnist.yml:15, gaussmix.yml:16) with
+// up to 32 classes.  On the GEMM back end such a head is five tiny launches per timestep (85 us, launch/latency
+// bound); here one launch runs all T timesteps, in the form of card_guided.hip's cooperative kernel:
+//   * the four waves of a workgroup (one per SIMD) share a 32-chain tile; wave w owns features [32w, 32w+32) of every
+//     hidden layer and keeps its rows of W2, W3 (2 x 64 VGPRs), of lin1's y_t columns and of lin4 in registers
+//   * y_t (C values per chain) lives in a chain-major LDS tile ys[32][36]; layer 1 = hoisted static part
+//     c1 = b1 + W1[:, C:2C] . y_0_hat (once per tile) + W1[:, 0:C] . y_t on MFMA each step (class order 8q + 4h + e, so
+//     one ds_read_b128 of ys feeds four k-steps), then softplus(BN1(gamma1 * .)) and the Hadamard product with this
+//     wave's 32 features of x_feat (registers, loaded once per tile)
+//   * layers 2, 3 as in the regression kernel (activation exchange through a chain-major LDS tile)
+//   * lin4 on MFMA too: the accumulators of layer 3 are, register for register, the B operand of a 32-class x 32-chain
+//     tile with K = this wave's 32 features; the four waves' partial tiles are exchanged through LDS and added in wave
+//     order; wave w then updates classes [8w, 8w+8) of every chain (posterior update in the reference's fp32 order,
+//     noise per (chain, class) element) and writes them back to ys
+// Eval-mode BatchNorm is the per-feature affine folded into the gamma table (scale) and a shift table; softplus runs in
+// log2 units with ln2 folded into W2, W3, W4, exactly as in the other kernels.
+#include "card_internal.h"
+
+using namespace card;
+
+namespace {
+
+constexpr int kF = 128;            // feature width
+constexpr int kWaves = 4;
+constexpr int kThreads = kWaves * 64;
+constexpr int kTileM = 32;
+constexpr int kCmax = 32;          // classes, padded
+constexpr int kExLd = kF + 4;      // activation exchange row stride (floats)
+constexpr int kYLd = kCmax + 4;    // ys / partial-tile row stride
+constexpr int kGRow = 3 * kF;
+constexpr int kTab = 6 * kF + kCmax;                 // b1|b2|b3 | shift1|shift2|shift3 (log2 units) | b4
+constexpr int kLdsFloats = 2 * kTileM * kExLd + kTileM * kYLd + kWaves * kTileM * kYLd + 2 * kGRow + kTab;
+constexpr int kPrioValu = 3, kPrioMfma = 0;
+
+}  // namespace
+
+struct ClsCoopParams {
+    const float* wpk;     // W2 | W3 fragment images (x ln2)
+    const float* w1f;     // lin1 fragments: [part(dyn, stat)][wave][q][64][4]
+    const float* w4f;     // lin4 fragments: [wave][q][64][4] (x ln2)
+    const float* tabs;    // kTab floats
+    const float* gtab;    // (n_embed, 3, 128) gamma * bn_scale * log2e
+    const float* coef;
+    const float* xfeat;   // (rows, 128)
+    const float* y0hat;   // (rows, C)
+    const float* ytmean;
+    const float* y_init;  // (N, C) or NULL
+    const float* noise;
+    float* out;
+    const int* state_slot;
+    long long N;
+    unsigned long long seed, elem_offset;
+    int T, t_hi, t_lo;
+    int C, nq1, guidance;
+    int out_mode, eps_only, n_z;
+};
+
+namespace {
+
+// BN affine + softplus of a 32-feature x 32-chain tile, staged over its 16 registers (see card_guided.hip)
+__device__ __forceinline__ void epilogue_bn(f32x16& acc, const float* gl, const float* sl) {
+    float xs[16], e[16];
+    __builtin_amdgcn_s_setprio(kPrioValu);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 g = lds4(gl + 8 * q), sh = lds4(sl + 8 * q);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xs[4 * q + k] = fmaf(acc[4 * q + k], g[k], sh[k]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(xs[r]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) e[r] = 1.0f + e[r];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_logf(e[r]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = __builtin_amdgcn_fmed3f(e[r], xs[r], kSpThresh);
+    __builtin_amdgcn_s_setprio(kPrioMfma);
+}
+
+__global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const ClsCoopParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const ex = lds;                                   // 2 x [32][132] activations
+    float* const ys = ex + 2 * kTileM * kExLd;               // [32][36] y_t, chain-major
+    float* const red = ys + kTileM * kYLd;                   // [4][32][36] lin4 partial tiles
+    float* const gsl = red + kWaves * kTileM * kYLd;         // 2 gamma rows
+    float* const tab = gsl + 2 * kGRow;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31, hh = lane >> 5;
+    const int C = p.C;
+    for (int i = tid; i < kTab; i += kThreads) tab[i] = p.tabs[i];
+
+    // register-resident A fragments of this wave: W2, W3 rows, lin1's y_t columns, lin4's columns
+    float A2[64], A3[64], A1[16], A4[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p.wpk + ((w * 16 + i) * 64 + lane) * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.wpk + kF * kF + ((w * 16 + i) * 64 + lane) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { A2[4 * i + e] = a[e]; A3[4 * i + e] = b[e]; }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (q < p.nq1) a = *reinterpret_cast<const f32x4*>(p.w1f + ((w * p.nq1 + q) * 64 + lane) * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.w4f + ((w * 4 + q) * 64 + lane) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { A1[4 * q + e] = a[e]; A4[4 * q + e] = b[e]; }
+    }
+    __syncthreads();
+    const float* const tb = tab + 32 * w + 4 * hh;                      // bias of this wave's features: + layer*128 + 8q
+    const float* const ts = tab + 3 * kF + 32 * w + 4 * hh;             // shift
+    float* const exw = ex + m * kExLd + 32 * w + 4 * hh;
+    const float* const exr = ex + m * kExLd + 4 * hh;
+    const int c0 = 8 * w + 4 * hh;                                       // first of the 4 classes this lane updates
+    float* const ysw = ys + m * kYLd + c0;
+    const float* const ysr = ys + m * kYLd + 4 * hh;
+    const f32x4 b4v = lds4(tab + 6 * kF + c0);
+
+    const long long n_tiles = (p.N + kTileM - 1) / kTileM;
+    const int T = p.T;
+    const int draw0 = p.y_init ? (T - p.t_hi) : 0;
+    const int slot_base = draw0;
+    const long long NC = p.N * C;
+    int gcur = 0;
+
+    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const long long row = tile * kTileM + m;
+        const bool valid = row < p.N;
+        const long long rc = valid ? row : p.N - 1;
+        const long long rr = p.n_z > 1 ? rc / p.n_z : rc;
+        // hoisted static part of layer 1 and this wave's x_feat block
+        f32x16 c1, xf;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = lds4(tb + 8 * q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                c1[4 * q + k] = b[k];
+                xf[4 * q + k] = p.xfeat[rr * kF + 32 * w + 8 * q + 4 * hh + k];
+            }
+        }
+        if (p.guidance) {
+            for (int q = 0; q < p.nq1; ++q) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(p.w1f + (((kWaves + w) * p.nq1 + q) * 64 + lane) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 8 * q + 4 * hh + e;
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], c < C ? p.y0hat[rr * C + c] : 0.0f, c1, 0, 0, 0);
+                }
+            }
+        }
+        // the 4 (chain, class) elements this lane owns
+        float yv[4], mu[4], zc[4][4];
+        uint32_t zblock = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mu[k] = c0 + k < C ? p.ytmean[rr * C + c0 + k] : 0.0f;
+        auto draw = [&](int d, float (&z)[4]) {
+            if (p.noise) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) z[k] = c0 + k < C ? p.noise[(long long)(d - draw0) * NC + rc * C + c0 + k] : 0.0f;
+                return;
+            }
+            const uint32_t blk = (uint32_t)d >> 2;
+            if (blk != zblock) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    philox_normal4(p.seed, p.elem_offset + (unsigned long long)(rc * C + (c0 + k < C ? c0 + k : 0)), blk, zc[k]);
+                zblock = blk;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) z[k] = pick4(zc[k], d & 3);
+        };
+        auto store_state = [&](int s) {
+            long long slot;
+            if (p.out_mode == CARD_OUT_ALL) slot = s - slot_base;
+            else if (p.out_mode == CARD_OUT_SELECT) slot = p.state_slot[s];
+            else return;
+            if (slot < 0 || !valid) return;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (c0 + k < C) p.out[slot * NC + row * C + c0 + k] = yv[k];
+        };
+        if (p.y_init) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) yv[k] = c0 + k < C ? p.y_init[rc * C + c0 + k] : 0.0f;
+        } else {
+            float z[4];
+            draw(0, z);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) yv[k] = c0 + k < C ? z[k] + mu[k] : 0.0f;       // classification/diffusion_utils.py:123-124
+            store_state(0);
+        }
+        *reinterpret_cast<f32x4*>(ysw) = f32x4{yv[0], yv[1], yv[2], yv[3]};
+        for (int i = tid; i < kGRow; i += kThreads) gsl[gcur * kGRow + i] = p.gtab[(long long)p.t_hi * kGRow + i];
+        __syncthreads();
+
+        auto publish = [&](const f32x16& a, int buf) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<f32x4*>(exw + buf * kTileM * kExLd + 8 * q) = f32x4{a[4 * q + 0], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+        };
+        auto hidden = [&](const float (&A)[64], int buf, int layer, const float* gl) -> f32x16 {
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b = lds4(tb + layer * kF + 8 * q);
+                acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const f32x4 h = lds4(exr + buf * kTileM * kExLd + 32 * (i >> 2) + 8 * (i & 3));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * i + e], h[e], acc, 0, 0, 0);
+            }
+            epilogue_bn(acc, gl + layer * kF + 32 * w, ts + layer * kF);
+            return acc;
+        };
+
+        for (int t = p.t_hi; t >= p.t_lo; --t) {
+            const bool more = t > p.t_lo;
+            f32x4 gn = {0.f, 0.f, 0.f, 0.f};
+            if (more && tid < kGRow / 4) gn = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(t - 1) * kGRow + tid * 4);
+            float z[4] = {0.f, 0.f, 0.f, 0.f};
+            if (t >= 1 && !p.eps_only) draw(T - t, z);
+            const float* const gl = gsl + gcur * kGRow + 4 * hh;
+
+            // layer 1 (model.py:82-87): c1 + W1[:, 0:C] . y_t, BN, softplus, Hadamard with x_feat
+            f32x16 acc = c1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < p.nq1) {
+                    const f32x4 yb = lds4(ysr + 8 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[4 * q + e], yb[e], acc, 0, 0, 0);
+                }
+            }
+            epilogue_bn(acc, gl + 32 * w, ts);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] *= xf[r];
+            publish(acc, 0);
+            __syncthreads();
+            acc = hidden(A2, 0, 1, gl);
+            publish(acc, 1);
+            __syncthreads();
+            acc = hidden(A3, 1, 2, gl);
+            if (more && tid < kGRow / 4) *reinterpret_cast<f32x4*>(gsl + (gcur ^ 1) * kGRow + tid * 4) = gn;
+            // lin4 (model.py:94): this wave's K = 32 slice of the 32-class x 32-chain tile
+            f32x16 part;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[r] = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part = __builtin_amdgcn_mfma_f32_32x32x2f32(A4[r], acc[r], part, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<f32x4*>(red + (w * kTileM + m) * kYLd + 8 * q + 4 * hh) =
+                    f32x4{part[4 * q + 0], part[4 * q + 1], part[4 * q + 2], part[4 * q + 3]};
+            __syncthreads();
+            f32x4 eps = lds4(red + m * kYLd + c0);
+#pragma unroll
+            for (int ww = 1; ww < kWaves; ++ww) {
+                const f32x4 v = lds4(red + (ww * kTileM + m) * kYLd + c0);
+                eps += v;
+            }
+            eps += b4v;
+            gcur ^= more ? 1 : 0;
+
+            if (p.eps_only) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (valid && c0 + k < C) p.out[row * C + c0 + k] = eps[k];
+                break;
+            }
+            // posterior update per (chain, class), classification/diffusion_utils.py:80-86 (t >= 1) / :98-100 (t == 0)
+            const float* c = p.coef + (long long)t * CARD_COEF_COLS;
+            const float ci = c[CARD_COEF_INV_SQRT_AB], co = c[CARD_COEF_ONE_M_SQRT_AB], cs = c[CARD_COEF_SOMAB];
+            const float g0 = c[CARD_COEF_G0], g1 = c[CARD_COEF_G1], g2 = c[CARD_COEF_G2], sg = c[CARD_COEF_SIGMA];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float y0r = ci * ((yv[k] - co * mu[k]) - eps[k] * cs);
+                float v = y0r;
+                if (t >= 1) v = ((g0 * y0r + g1 * yv[k]) + g2 * mu[k]) + sg * z[k];
+                yv[k] = c0 + k < C ? v : 0.0f;
+            }
+            store_state(T - t);
+            *reinterpret_cast<f32x4*>(ysw) = f32x4{yv[0], yv[1], yv[2], yv[3]};
+            __syncthreads();
+        }
+        if (p.out_mode == CARD_OUT_LAST && !p.eps_only && valid) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (c0 + k < C) p.out[row * C + c0 + k] = yv[k];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// create-time packing
+// ------------------------------------------------------------------------------------------------
+// W2 / W3: element e of lane l in block (j, i = 4jj + q) is W[32j + (l&31)][32jj + 8q + 4(l>>5) + e] * ln2
+__global__ void cls_pack_hidden_kernel(const float* __restrict__ W, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= kF * kF) return;
+    const int e = idx & 3, l = (idx >> 2) & 63, q = (idx >> 8) & 3, jj = (idx >> 10) & 3, j = idx >> 12;
+    out[idx] = W[(32 * j + (l & 31)) * kF + 32 * jj + 8 * q + 4 * (l >> 5) + e] * kLn2;
+}
+
+// lin1: part 0 = y_t columns [0, C), part 1 = y_0_hat columns [C, 2C); k-step (q, e) of lane half h takes class 8q + 4h + e
+__global__ void cls_pack_first_kernel(const float* __restrict__ W1, int C, int d_in, int nq1, float* __restrict__ out) {
+    const int total = 2 * kWaves * nq1 * 256;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int e = idx & 3, l = (idx >> 2) & 63, rest = idx >> 8, q = rest % nq1, j = (rest / nq1) % kWaves, part = rest / (nq1 * kWaves);
+        const int c = 8 * q + 4 * (l >> 5) + e, col = part * C + c;
+        out[idx] = (c < C && col < d_in) ? W1[(32 * j + (l & 31)) * d_in + col] : 0.0f;
+    }
+}
+
+// lin4: A[class = l&31][k]: k-step (q, e) of lane half h takes feature 32w + 8q + 4h + e (layer 3's accumulator order)
+__global__ void cls_pack_head_kernel(const float* __restrict__ W4, int C, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= kWaves * 4 * 256) return;
+    const int e = idx & 3, l = (idx >> 2) & 63, q = (idx >> 8) & 3, j = idx >> 10;
+    const int cls = l & 31;
+    out[idx] = cls < C ? W4[cls * kF + 32 * j + 8 * q + 4 * (l >> 5) + e] * kLn2 : 0.0f;
+}
+
+__global__ void cls_pack_tabs_kernel(const float* b1, const float* b2, const float* b3, const float* s1, const float* s2,
+                                     const float* s3, const float* b4, int C, float* __restrict__ tabs) {
+    const int i = threadIdx.x;   // 128 threads
+    tabs[i] = b1[i]; tabs[kF + i] = b2[i]; tabs[2 * kF + i] = b3[i];
+    tabs[3 * kF + i] = s1[i] * kLog2e; tabs[4 * kF + i] = s2[i] * kLog2e; tabs[5 * kF + i] = s3[i] * kLog2e;
+    if (i < kCmax) tabs[6 * kF + i] = i < C ? b4[i] : 0.0f;
+}
+
+__global__ void cls_pack_gamma_kernel(const float* g1, const float* g2, const float* g3, const float* s1, const float* s2,
+                                      const float* s3, int n_embed, float* __restrict__ gtab) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_embed * kGRow) return;
+    const int t = idx / kGRow, r = idx % kGRow, l = r / kF, n = r % kF;
+    gtab[idx] = (l == 0 ? g1 : (l == 1 ? g2 : g3))[t * kF + n] * (l == 0 ? s1 : (l == 1 ? s2 : s3))[n] * kLog2e;
+}
+
+}  // namespace
+
+bool clscoop_supports(const card_model_desc* d) {
+    if (const char* ev = getenv("CARD_AMD_CLSCOOP"))
+        if (ev[0] == '0') return false;                 // A/B: GEMM back end
+    return d->variant == CARD_VARIANT_BN_HADAMARD && d->hidden == kF && d->x_dim == kF && d->y_dim <= kCmax &&
+           d->bn_scale[0] && d->bn_scale[1] && d->bn_scale[2] && d->bn_shift[0] && d->bn_shift[1] && d->bn_shift[2];
+}
+
+int clscoop_create(card_sampler* s, const card_model_desc* d, hipStream_t stream) {
+    const int C = d->y_dim, nq1 = (C + 7) / 8, d_in = s->d_in;
+    s->nqs = nq1;
+    HIP_TRY(hipMalloc(&s->wpk, (size_t)2 * kF * kF * sizeof(float)));
+    HIP_TRY(hipMalloc(&s->w1s, (size_t)2 * kWaves * nq1 * 256 * sizeof(float)));
+    HIP_TRY(hipMalloc(&s->W4, (size_t)kWaves * 4 * 256 * sizeof(float)));
+    HIP_TRY(hipMalloc(&s->bias, (size_t)kTab * sizeof(float)));
+    HIP_TRY(hipMalloc(&s->gtab, (size_t)d->n_embed * kGRow * sizeof(float)));
+    s->lds_bytes = (size_t)kLdsFloats * sizeof(float);
+    HIP_TRY(hipFuncSetAttribute((const void*)card_sample_cls_coop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
+    int nb = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)card_sample_cls_coop_kernel, kThreads, s->lds_bytes));
+    s->coop_blocks = nb < 1 ? 1 : (nb > 2 ? 2 : nb);
+    cls_pack_hidden_kernel<<<kF * kF / 256, 256, 0, stream>>>(d->W[1], s->wpk);
+    cls_pack_hidden_kernel<<<kF * kF / 256, 256, 0, stream>>>(d->W[2], s->wpk + kF * kF);
+    cls_pack_first_kernel<<<8, 256, 0, stream>>>(d->W[0], C, d_in, nq1, s->w1s);
+    cls_pack_head_kernel<<<kWaves * 4, 256, 0, stream>>>(d->W4, C, s->W4);
+    cls_pack_tabs_kernel<<<1, kF, 0, stream>>>(d->b[0], d->b[1], d->b[2], d->bn_shift[0], d->bn_shift[1], d->bn_shift[2], d->b4, C, s->bias);
+    const int ng = d->n_embed * kGRow;
+    cls_pack_gamma_kernel<<<(ng + 255) / 256, 256, 0, stream>>>(d->gamma[0], d->gamma[1], d->gamma[2], d->bn_scale[0],
+                                                              d->bn_scale[1], d->bn_scale[2], d->n_embed, s->gtab);
+    HIP_TRY(hipGetLastError());
+    return CARD_OK;
+}
+
+void clscoop_destroy(card_sampler* s) {
+    float* bufs[] = {s->wpk, s->w1s, s->W4, s->bias, s->gtab};
+    for (float* b : bufs)
+        if (b) (void)hipFree(b);
+}
+
+int clscoop_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
+    ClsCoopParams p;
+    memset(&p, 0, sizeof(p));
+    p.wpk = s->wpk; p.w1f = s->w1s; p.w4f = s->W4; p.tabs = s->bias; p.gtab = s->gtab; p.coef = r.coef;
+    p.xfeat = r.x; p.y0hat = r.y0hat; p.ytmean = r.ytmean; p.y_init = r.y_init; p.noise = r.noise; p.out = r.out;
+    p.state_slot = r.state_slot; p.N = r.N; p.seed = r.seed; p.elem_offset = r.elem_offset;
+    p.T = r.T; p.t_hi = r.t_hi; p.t_lo = r.t_lo; p.C = s->y_dim; p.nq1 = s->nqs; p.guidance = s->cat_y_pred;
+    p.out_mode = r.out_mode; p.eps_only = r.eps_only; p.n_z = r.n_z;
+    const long long tiles = (r.N + kTileM - 1) / kTileM;
+    const long long cap = (long long)s->num_cu * s->coop_blocks;
+    const long long grid = tiles < cap ? tiles : cap;
+    card_sample_cls_coop_kernel<<<dim3((unsigned)grid), dim3(kThreads), s->lds_bytes, stream>>>(p);
+    HIP_TRY(hipGetLastError());
+    return CARD_OK;
+}

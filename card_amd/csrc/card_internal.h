@@ -25,7 +25,7 @@ struct card_sampler {
     int variant, x_dim, y_dim, hidden, n_embed, cat_x, cat_y_pred;
     int d_in;
     int device, num_cu;
-    int backend;   // 0: persistent kernel (card_guided.hip), 1: streaming GEMMs (card_wide.hip), 2: persistent kernel with streamed weights (card_stream.hip)
+    int backend;   // 0: persistent kernel (card_guided.hip), 1: streaming GEMMs (card_wide.hip), 2: persistent kernel with streamed weights (card_stream.hip), 3: cooperative classification kernel (card_clscoop.hip)
     // ---- CARD_VARIANT_GUIDED (card_guided.hip)
     int k1, hoist, nqs;
     int coop_force;
@@ -58,4 +58,9 @@ bool stream_supports(const card_model_desc* d, int d_in);
 int stream_create(card_sampler* s, const card_model_desc* d, hipStream_t stream);
 void stream_destroy(card_sampler* s);
 int stream_run(const card_sampler* s, const CardRun& r, hipStream_t stream);
+
+bool clscoop_supports(const card_model_desc* d);
+int clscoop_create(card_sampler* s, const card_model_desc* d, hipStream_t stream);
+void clscoop_destroy(card_sampler* s);
+int clscoop_run(const card_sampler* s, const CardRun& r, hipStream_t stream);
 #endif

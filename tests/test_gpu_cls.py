@@ -43,6 +43,14 @@ def cuda(t):
     return t.to(DEV)
 
 
+@pytest.fixture(params=["coop", "gemm"], autouse=True)
+def f128_kernel(request, monkeypatch):
+    """F = 128 heads run on the cooperative persistent kernel by default (card_clscoop.hip); CARD_AMD_CLSCOOP=0 (read
+    when a sampler is created) keeps them on the GEMM back end.  Every test runs against both."""
+    monkeypatch.setenv("CARD_AMD_CLSCOOP", "1" if request.param == "coop" else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("name", CLS)
 def test_cls_loop_matches_reference(name):
     g = load_golden(name)
@@ -194,3 +202,26 @@ def test_loop_with_eval_hook_matches_full_trajectory(num_ts):
     for num_t, y in seen.items():
         assert torch.equal(y, full[num_t - 1]), num_t
     assert torch.equal(y0, full[T])
+
+
+def test_f128_cooperative_kernel_equals_gemm_backend_in_rng_mode(monkeypatch):
+    """Same seed, same (chain, class) Philox elements: the two back ends agree to rounding on a ragged multi-tile batch
+    with in-kernel row tiling, for C = 10 and C = 3, with and without guidance columns."""
+    for name, guidance in (("cls_mnist_T50", True), ("cls_gaussmix_T50", True)):
+        g = load_golden(name)
+        T = g["T"]
+        coef = cuda(make_coef_table(g["alphas"], g["omabs"]))
+        rows, n_z = 37, 50                                  # 1850 chains = 58 tiles, last one ragged
+        idx = torch.arange(rows) % g["x_feat"].shape[0]
+        xf, y0 = cuda(g["x_feat"][idx]), cuda(g["y0hat"][idx])
+        outs = []
+        for mode in ("1", "0"):
+            monkeypatch.setenv("CARD_AMD_CLSCOOP", mode)
+            s = Sampler.from_cls_state_dict(g["sd"], guidance=guidance, device=DEV)
+            assert (s._workspace(64)[2] == 0) == (mode == "1")      # the cooperative kernel needs no workspace
+            outs.append(s.run(xf, y0, y0, coef, T, seed=31, elem_offset=12345, n_z=n_z, out_mode=_lib.OUT_SELECT,
+                              states=[0, 1, T // 2, T]).cpu())
+        assert torch.equal(outs[0][0], outs[1][0])          # y_T = draw 0 + mean: identical
+        err = max(norm_rel_err(outs[0][k], outs[1][k]) for k in range(4))
+        print(f"{name}: cooperative vs GEMM back end {err:.3e}")
+        assert err <= TOL
