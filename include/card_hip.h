@@ -45,7 +45,9 @@ typedef enum card_variant {
        any other hidden that is a multiple of 128, any y_dim: streaming-GEMM back end (needs a workspace). */
     CARD_VARIANT_GUIDED = 0,
     /* classification/model.py:22-94 ConditionalModel after the hoisted encoder: eval-BatchNorm after each
-       ConditionalLinear and a Hadamard product with x_feat = norm(encoder_x(x)) after layer 1 */
+       ConditionalLinear and a Hadamard product with x_feat = norm(encoder_x(x)) after layer 1.
+       hidden = 128, y_dim <= 32 (MNIST / gaussmix configs): cooperative persistent kernel, no workspace;
+       any other hidden that is a multiple of 128: streaming-GEMM back end (needs a workspace). */
     CARD_VARIANT_BN_HADAMARD = 1,
     /* classification/imagenet/card/builder.py:69-92 ConditionalModel (ImageNet head): no BatchNorm, no softplus, two
        conditional layers: lin2(gamma2[t]) o ( linx(z) * (gamma1[t] * lin1(cat(y_t, y_0_hat))) ) then lin3.
