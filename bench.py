@@ -9,7 +9,7 @@ toy 8-Gaussians shape, 10 000 test rows x 1000 z-samples, x_dim=1 (d_in=3), H=12
 per GPU per step.  With N > 1 (torch.distributed.run, one rank per GPU, RCCL) every rank samples its own
 shard of rows (weak scaling, no data-path collective); the evaluation sums are all-reduced once per step.
 
-Other shapes of BASELINE.json's configs are presets (--workload boston | year | sweep | sweep256 | cifar10); networks
+Other shapes of BASELINE.json's configs are presets (--workload boston | year | sweep | sweep256 | mnist | cifar10); networks
 other than the reference's H=128 / y_dim=1 regression MLP run on the streaming-GEMM back end.
 
 Rank 0 prints ONE JSON line with the driver contract's fields plus `roofline` and `cpu_baseline`.
@@ -44,6 +44,9 @@ WORKLOADS = {
     "sweep256": ("guided", 100_000, 100, 13, 256, 1,
                  "synthetic rows x 100 z-samples, x_dim=13, hidden 256 (BASELINE configs[4], width-256 leg; 100k of the 1M "
                  "rows per GPU by default, --rows 1000000 for all)"),
+    "mnist": ("cls", 250, 100, 128, 128, 10,
+              "MNIST head shape (classification/configs/mnist.yml: F=128, C=10, 100 z-samples, one reference test batch of 250 "
+              "images per GPU; x_feat and y_0_hat synthetic)"),
     "cifar10": ("cls", 250, 100, 4096, 4096, 10,
                 "CIFAR-10 head shape (BASELINE configs[3]: F=4096, C=10, 100 z-samples; one reference test batch of 250 "
                 "images per GPU by default, cifar10.yml:66,:71; x_feat and y_0_hat synthetic)"),
@@ -133,6 +136,7 @@ def main():
         y0_rows = torch.softmax(torch.randn(a.rows, y_dim, generator=g) * 2, 1)
         y_true = None
     persistent = kind == "guided" and H in (128, 256)     # card_guided.hip / card_stream.hip; otherwise GEMM back end
+    cls_coop = kind == "cls" and H == 128 and y_dim <= 32  # card_clscoop.hip
     x, y0 = x_rows.to(dev), y0_rows.to(dev)
     elem_offset = rank * N * y_dim
     from card_amd.distributed import regression_metric_sums, all_reduce_sums
@@ -186,6 +190,10 @@ def main():
             chunk = cu * WAVES_PER_CU * TILES_PER_WAVE_PER_LAUNCH * TILE_M if H == 128 else cu * 8 * 128   # guided_run / stream_run
             launches = math.ceil(N / chunk) * a.steps
             kernel = "card_sample_guided_kernel" if H == 128 else "card_sample_stream_kernel"
+        elif cls_coop:
+            chunk = None
+            launches = a.steps
+            kernel = "card_sample_cls_coop_kernel"
         else:
             # GEMM back end: a timestep is 4 GEMM launches + 1 update launch per chunk of chains; the two F x F
             # wide_gemm_kernel<EPI_SOFTPLUS> launches carry > 95 % of the flops.  `achieved` below still divides the
@@ -230,7 +238,7 @@ def main():
                 w = orc.GuidedWeights.from_state_dict(sd)
                 xc, yc = torch.randn(rows_cpu, x_dim, generator=gc), torch.randn(rows_cpu, 1, generator=gc)
             else:
-                rows_cpu, steps_cpu = 2500, 4             # a tenth of one reference test batch (250 images x 100 z)
+                rows_cpu, steps_cpu = 2500, (4 if H >= 2048 else 200)   # a tenth of one reference test batch (250 images x 100 z)
                 w = orc.ClsWeights.from_state_dict(sd)
                 xc = torch.randn(rows_cpu, H, generator=gc)
                 yc = torch.softmax(torch.randn(rows_cpu, y_dim, generator=gc) * 2, 1)

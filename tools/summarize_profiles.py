@@ -7,7 +7,7 @@ os.makedirs("profiles", exist_ok=True)
 if os.path.exists("gpurun_out/ubench.txt"):
     open(f"profiles/{tag}_ubench.txt", "w").write(open("gpurun_out/ubench.txt").read())
 
-for name in ("bench", "cifar", "stream"):
+for name in ("bench", "cifar", "stream", "mnist"):
     for p in glob.glob(f"gpurun_out/prof_{name}/*/*kernel_stats.csv"):
         rows = list(csv.reader(open(p)))
         keep = [rows[0]] + [r for r in rows[1:] if "card" in r[0] or "wide_" in r[0] or "pack" in r[0]]
