@@ -675,7 +675,7 @@ int guided_create(card_sampler* s, const card_model_desc* d, hipStream_t stream)
     const int nqs = (d_in - 1 + 7) / 8;
     sample_kernel_t kern = guided_kernel_for(k1, hoist ? 1 : 0);
     if (!kern) return card_fail(CARD_E_UNSUPPORTED, "card_sampler_create: no kernel for d_in=%d", d_in);
-    s->k1 = k1; s->kernel = kern; s->hoist = hoist ? 1 : 0; s->nqs = nqs;
+    s->k1 = k1; s->kernel = reinterpret_cast<void*>(kern); s->hoist = hoist ? 1 : 0; s->nqs = nqs;
     const int img = img_floats(k1);
     s->lds_bytes = (size_t)(img + kWaves * kGammaRow + (hoist ? kWaves * 2 * kH : 0)) * sizeof(float);
     HIP_TRY(hipMalloc(&s->wpk, (size_t)img * sizeof(float)));
@@ -751,7 +751,7 @@ int guided_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
         const long long tiles = (p.n_end - p.n_begin + kTileM - 1) / kTileM;
         const long long grid = tiles < s->num_cu ? tiles : s->num_cu;
         // in-kernel row tiling with n_z >= 32: the hoisted layer-1 tile has two distinct columns -> LDS-resident form
-        sample_kernel_t kern = (s->hoist && r.n_z >= 32) ? guided_kernel_for(s->k1, 2) : s->kernel;
+        sample_kernel_t kern = (s->hoist && r.n_z >= 32) ? guided_kernel_for(s->k1, 2) : reinterpret_cast<sample_kernel_t>(s->kernel);
         kern<<<dim3((unsigned)grid), dim3(kThreads), s->lds_bytes, stream>>>(p);
         HIP_TRY(hipGetLastError());
     }

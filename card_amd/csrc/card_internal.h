@@ -34,7 +34,7 @@ struct card_sampler {
     float* gtab;   // (n_embed, 3, H) gamma * log2e [* bn_scale]
     float* w1s;    // hoist: packed static columns of W1
     float* ws;     // hoist: per-wave scratch slots (num_cu * 8 * 16 KB)
-    void (*kernel)(const struct GuidedParams);
+    void* kernel;         // the back end's __global__ function for this model shape (cast back by its owner)
     size_t lds_bytes;
     // ---- GEMM back end (card_wide.hip): BN_HADAMARD, LINEAR_HADAMARD, and GUIDED at hidden != 128 or y_dim != 1
     float* W1;     // (F, d_in)

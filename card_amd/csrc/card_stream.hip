@@ -374,7 +374,7 @@ int stream_create(card_sampler* s, const card_model_desc* d, hipStream_t stream)
     if (!kern) return card_fail(CARD_E_UNSUPPORTED, "card_sampler_create: no streamed kernel for hidden=%d d_in=%d", H, d_in);
     const int ns1 = (ks1 + kSlabKs - 1) / kSlabKs, NSH = H / 32, SLAB = kSlabKs * (H / 16) * 64;
     s->k1 = ks1;
-    s->kernel = reinterpret_cast<void (*)(const GuidedParams)>(kern);
+    s->kernel = reinterpret_cast<void*>(kern);
     s->lds_bytes = (size_t)(3 * SLAB + 4 * H + 4 + 2 * 3 * H) * sizeof(float);
     HIP_TRY(hipMalloc(&s->wpk, (size_t)(ns1 + 2 * NSH) * SLAB * sizeof(float)));
     HIP_TRY(hipMalloc(&s->w1s, (size_t)(4 * H + 4) * sizeof(float)));
