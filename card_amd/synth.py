@@ -24,11 +24,11 @@ def guided_state_dict(x_dim, T, seed=1234, *, y_dim=1, hidden=128, cat_x=True, c
     return sd
 
 
-def cls_state_dict(F, C, T, seed):
+def cls_state_dict(F, C, T, seed, guidance=True):
     """classification/model.py:40 ConditionalModel theta part (lin1..lin4, unetnorm1..3 with non-trivial statistics)."""
     gen = torch.Generator().manual_seed(seed)
     sd = {}
-    for k, i in (("lin1", 2 * C), ("lin2", F), ("lin3", F)):
+    for k, i in (("lin1", 2 * C if guidance else C), ("lin2", F), ("lin3", F)):
         _linear(sd, gen, k + ".lin", i, F)
         sd[k + ".embed.weight"] = torch.rand(T + 1, F, generator=gen)
     _linear(sd, gen, "lin4", F, C, 0.1)

@@ -225,3 +225,26 @@ def test_f128_cooperative_kernel_equals_gemm_backend_in_rng_mode(monkeypatch):
         err = max(norm_rel_err(outs[0][k], outs[1][k]) for k in range(4))
         print(f"{name}: cooperative vs GEMM back end {err:.3e}")
         assert err <= TOL
+
+
+@pytest.mark.parametrize("F,C", [(128, 10), (128, 32), (128, 5), (256, 10)])
+def test_cls_without_guidance_and_class_count_edges(F, C):
+    """ConditionalModel(guidance=False) (classification/model.py:31: lin1 sees y_t alone) and class counts at the
+    edges of the cooperative kernel's 8-class groups, against the oracle on seeded weights."""
+    T, N = 8, 70
+    alphas, _, omabs = orc.make_schedule("linear", T, 1e-4, 0.3)
+    coef = cuda(make_coef_table(alphas, omabs))
+    for guidance in (False, True):
+        sd = cls_state_dict(F, C, T, 9, guidance=guidance)
+        w = orc.ClsWeights.from_state_dict(sd, guidance=guidance)
+        gen = torch.Generator().manual_seed(10)
+        xf = torch.randn(N, F, generator=gen)
+        y0 = torch.softmax(torch.randn(N, C, generator=gen) * 2, 1)
+        noise = torch.randn(T, N, C, generator=gen)
+        want = torch.stack(orc.p_sample_loop(w, xf, y0, y0, T, alphas, omabs, noise), 0)
+        s = Sampler.from_cls_state_dict(sd, guidance=guidance, device=DEV)
+        got = s.run(cuda(xf), cuda(y0), cuda(y0), coef, T, noise=cuda(noise), out_mode=_lib.OUT_ALL).cpu()
+        worst = max(norm_rel_err(got[k], want[k]) for k in range(T + 1))
+        assert worst <= TOL, (guidance, worst)
+        eps = s.eps_theta(cuda(xf), cuda(want[2]), cuda(y0), 3).cpu()
+        assert norm_rel_err(eps, orc.eps_theta(w, xf, want[2], y0, 3)) <= TOL
