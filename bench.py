@@ -103,8 +103,7 @@ def main():
 
     from card_amd import _lib
     from card_amd.sampler import Sampler, make_coef_table
-    from card_amd.synth import guided_state_dict, cls_state_dict
-    from oracle.card_oracle import make_schedule   # schedule constructor only (host-side setup, not measured)
+    from card_amd.synth import guided_state_dict, cls_state_dict, make_schedule
 
     kind, p_rows, p_nz, p_xdim, p_hidden, y_dim, desc = WORKLOADS[a.workload]
     a.rows = p_rows if a.rows is None else a.rows

@@ -5,6 +5,8 @@ import math
 
 import torch
 
+from .diffusion_utils import make_beta_schedule
+
 
 def _linear(sd, gen, name, i, o, scale=1.0):
     b = 1.0 / math.sqrt(i)
@@ -39,3 +41,15 @@ def cls_state_dict(F, C, T, seed, guidance=True):
         sd[f"unetnorm{i}.running_var"] = torch.rand(F, generator=gen) + 0.5
         sd[f"unetnorm{i}.num_batches_tracked"] = torch.tensor(0)
     return sd
+
+
+def make_schedule(schedule="linear", T=1000, start=1e-4, end=0.02):
+    """(alphas, alphas_bar_sqrt, one_minus_alphas_bar_sqrt) the way the reference's runner derives them from the beta
+    schedule (Diffusion.__init__, regression/card_regression.py:39-50), on the CPU."""
+    betas = make_beta_schedule(schedule, T, start, end).float()
+    alphas = 1.0 - betas
+    alphas_cumprod = alphas.cumprod(dim=0)
+    omabs = torch.sqrt(1 - alphas_cumprod)
+    if schedule == "cosine":
+        omabs = omabs * 0.9999
+    return alphas, torch.sqrt(alphas_cumprod), omabs

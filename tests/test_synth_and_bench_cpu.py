@@ -47,3 +47,30 @@ def test_bench_presets_are_well_formed():
         if kind == "cls":
             assert x_dim == hidden                          # x is x_feat
     assert presets["toy"][1] * presets["toy"][2] == 10_000 * 1000
+
+
+def test_product_schedule_helper_matches_the_oracle():
+    from card_amd.synth import make_schedule
+    for kind, T, lo, hi in (("linear", 1000, 1e-4, 0.02), ("linear", 50, 1e-4, 0.4), ("cosine", 100, 1e-4, 0.02)):
+        for a, b in zip(make_schedule(kind, T, lo, hi), orc.make_schedule(kind, T, lo, hi)):
+            assert torch.equal(a, b)
+
+
+def test_oracle_is_imported_only_where_allowed():
+    """oracle/ is test infrastructure: the package and the tools never import it; bench.py only inside its cpu_baseline leg."""
+    import re
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b", re.M)
+    for d in ("card_amd", "tools"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, d)):
+            for f in files:
+                if f.endswith(".py"):
+                    assert not pat.search(open(os.path.join(dirpath, f)).read()), os.path.join(dirpath, f)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
+    for node in ast.walk(main):
+        if isinstance(node, (ast.Import, ast.ImportFrom)) and "oracle" in ast.unparse(node):
+            seg = ast.get_source_segment(src, node)
+            # the only import of the oracle inside main() sits under the `not a.no_cpu_baseline` branch
+            line = src[:src.index(seg)].count("\n")
+            assert "cpu_baseline" in "\n".join(src.splitlines()[line - 12:line + 12]), seg

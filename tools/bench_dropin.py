@@ -6,8 +6,7 @@ import json, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import card_amd
-from card_amd.synth import guided_state_dict
-from oracle.card_oracle import make_schedule
+from card_amd.synth import guided_state_dict, make_schedule
 
 dev, T, x_dim = "cuda:0", 1000, 13
 

@@ -7,8 +7,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from card_amd import _lib
 from card_amd.sampler import Sampler, make_coef_table
-from card_amd.synth import guided_state_dict
-from oracle.card_oracle import make_schedule
+from card_amd.synth import guided_state_dict, make_schedule
 
 dev, T, x_dim = "cuda:0", 1000, 13
 sd = guided_state_dict(x_dim, T)

@@ -8,8 +8,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from card_amd import _lib
 from card_amd.sampler import Sampler, make_coef_table
-from oracle.card_oracle import make_schedule
-from card_amd.synth import cls_state_dict
+from card_amd.synth import cls_state_dict, make_schedule
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=250); ap.add_argument("--nz", type=int, default=100)
