@@ -88,3 +88,20 @@ def test_no_gpu_fails_loudly():
     with pytest.raises(_lib.CardError):
         card_amd.p_sample_loop(m.eval(), torch.zeros(1, 1), torch.zeros(1, 1), torch.zeros(1, 1), 10,
                                torch.ones(10), torch.ones(10))
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """No built library -> CardError on first use, never a CPU / eager fallback."""
+    import subprocess, sys, os
+    code = ("import torch, card_amd\n"
+            "from card_amd._lib import CardError\n"
+            "try:\n"
+            "    card_amd.sampler.make_coef_table(torch.ones(4), torch.full((4,), 0.5))\n"
+            "except CardError as e:\n"
+            "    print('CardError:', e)\n"
+            "else:\n"
+            "    raise SystemExit('no error raised')\n")
+    env = dict(os.environ, CARD_AMD_LIB=str(tmp_path / "nope.so"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "CardError" in out.stdout, out.stdout + out.stderr
