@@ -2,6 +2,7 @@
 // One "step" = two 128x128 layers on a 32-chain tile (512 MFMAs), in variants that drop one ingredient each.
 //   bit 0: A fragments from LDS (else a constant register)     bit 1: softplus epilogue (else plain copy)
 //   bit 2: dependent chain per output tile (else 4 interleaved accumulators, one per output tile)
+//   bit 3: A fragments pinned one group ahead   bit 4: epilogue staged over the tile   bit 5 / 6: s_setprio around the epilogue
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include "../../card_amd/csrc/card_common.h"
@@ -46,13 +47,42 @@ __global__ __launch_bounds__(512, 2) void k(int steps, float* out, unsigned long
                         for (int e = 0; e < 4; ++e)
                             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], h[i >> 2][4 * (i & 3) + e], acc, 0, 0, 0);
                     }
-                    if constexpr (V & 2) {
+                    if constexpr ((V & 2) && !(V & 16)) {
+                        if constexpr (V & 32) __builtin_amdgcn_s_setprio(3);
+                        if constexpr (V & 64) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const f32x4 g = lds4(gl + 32 * j + 8 * q);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) acc[4 * q + e] = softplus_l2(acc[4 * q + e] * g[e]);
                         }
+                        if constexpr (V & 32) __builtin_amdgcn_s_setprio(0);
+                        if constexpr (V & 64) __builtin_amdgcn_s_setprio(3);
+                    }
+                    if constexpr ((V & 2) && (V & 16)) {
+                        if constexpr (V & 32) __builtin_amdgcn_s_setprio(3);
+                        if constexpr (V & 64) __builtin_amdgcn_s_setprio(0);
+                        float xs[16], ev[16];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 g = lds4(gl + 32 * j + 8 * q);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) xs[4 * q + e] = acc[4 * q + e] * g[e];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) ev[r] = __builtin_amdgcn_exp2f(xs[r]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) ev[r] = 1.0f + ev[r];
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) ev[r] = __builtin_amdgcn_logf(ev[r]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[r] = __builtin_amdgcn_fmed3f(ev[r], xs[r], kSpThresh);
+                        if constexpr (V & 32) __builtin_amdgcn_s_setprio(0);
+                        if constexpr (V & 64) __builtin_amdgcn_s_setprio(3);
                     }
                     o[j] = acc;
                 }
@@ -126,6 +156,10 @@ int main() {
         run<7>("chain, LDS A, softplus epilogue (kernel)", waves);
         run<13>("chain, LDS A prefetched, no epilogue", waves);
         run<15>("chain, LDS A prefetched, softplus epilogue", waves);
+        run<15 + 16>("  + staged epilogue", waves);
+        run<15 + 32>("  + epilogue at raised priority", waves);
+        run<15 + 16 + 32>("  + staged, epilogue at raised priority", waves);
+        run<15 + 16 + 64>("  + staged, MFMA chain at raised priority", waves);
         run<0>("4 accumulators, reg A, no epilogue", waves);
         run<1>("4 accumulators, LDS A, no epilogue", waves);
         run<3>("4 accumulators, LDS A, softplus epilogue", waves);
