@@ -245,6 +245,12 @@ def main():
             out["cpu_baseline"] = {"value": v, "unit": "sample-steps/s", "cores": threads, "kind": "port",
                                    "sample": f"{steps_cpu} of the {T} timesteps of one reference minibatch "
                                              f"({rows_cpu} chains), torch CPU fp32, {dt:.1f} s"}
+            if threads > 4:
+                # the reference's own default, torch.set_num_threads(args.thread = 4) (regression/main.py:25, :259-261)
+                torch.set_num_threads(4)
+                v4, _ = cpu_baseline(w, xc, yc, T, max(2, steps_cpu // 4), alphas, omabs)
+                torch.set_num_threads(threads)
+                out["cpu_baseline"]["at_reference_default_threads"] = {"cores": 4, "value": v4}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
