@@ -6,14 +6,16 @@ There is no CPU or eager-PyTorch fallback: without the built library, or without
 """
 from .diffusion_utils import (  # noqa: F401
     extract,
+    kld,
     make_beta_schedule,
     p_sample,
     p_sample_loop,
     p_sample_loop_with_eval,
+    p_sample_loop_with_y,
     p_sample_t_1to0,
     q_sample,
     y_0_reparam,
 )
-from .sampler import Sampler, sampler_for  # noqa: F401
+from .sampler import Sampler, invalidate, sampler_for  # noqa: F401
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"

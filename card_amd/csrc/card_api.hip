@@ -11,12 +11,16 @@ namespace {
 thread_local char g_err[512] = "";
 __global__ void q_sample_kernel(const float* __restrict__ y, const float* __restrict__ y0hat,
                                 const float* __restrict__ sab, const float* __restrict__ somab,
-                                const int64_t* __restrict__ t, long long n_elems, int y_dim,
+                                const int64_t* __restrict__ t, long long n_elems, int y_dim, int T,
                                 const float* __restrict__ noise, unsigned long long seed,
                                 unsigned long long elem_offset, float* __restrict__ out) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_elems;
          i += (long long)gridDim.x * blockDim.x) {
         const int64_t ti = t[i / y_dim];
+        if (ti < 0 || ti >= T) {                 // torch.gather raises here; a kernel cannot: poison, never read out of bounds
+            out[i] = __builtin_nanf("");
+            continue;
+        }
         const float a = sab[ti], s = somab[ti];
         float e;
         if (noise) {
@@ -46,6 +50,27 @@ __global__ void philox_fill_kernel(unsigned long long seed, unsigned long long e
             out[(long long)k * n_elems + i] = pick4(z, d & 3);
         }
     }
+}
+
+// Position-weighted 64-bit sum of the raw bits of up to kHashMax device arrays: order-independent across threads
+// (so atomics are fine), sensitive to which element changed (a permutation or a swap of two tensors changes it).
+constexpr int kHashMax = 32;
+struct HashArgs {
+    const uint32_t* ptr[kHashMax];
+    long long count[kHashMax];
+    int n;
+};
+__global__ __launch_bounds__(256) void content_hash_kernel(const HashArgs a, unsigned long long* __restrict__ out) {
+    unsigned long long h = 0;
+    for (int k = 0; k < a.n; ++k) {
+        const uint32_t* p = a.ptr[k];
+        const unsigned long long salt = 0x9E3779B97F4A7C15ull * (unsigned long long)(k + 1);
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.count[k]; i += (long long)gridDim.x * blockDim.x)
+            h += ((unsigned long long)p[i] + 0x632BE59BD9B4E019ull) * ((unsigned long long)(2 * i + 1) * 0xD6E8FEB86659FD93ull + salt);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o, 64);
+    if ((threadIdx.x & 63) == 0 && h != 0) atomicAdd(out, h);
 }
 
 }  // namespace
@@ -176,6 +201,29 @@ extern "C" CARD_API int card_sampler_run(const card_sampler* s, const card_run_a
          : s->backend == 3 ? clscoop_run(s, r, (hipStream_t)stream) : wide_run(s, r, (hipStream_t)stream);
 }
 
+extern "C" CARD_API int card_content_hash(const void* const* arrays, const int64_t* n_words, int32_t n_arrays, uint64_t* out,
+                                          void* stream) {
+    if (!arrays || !n_words || !out || n_arrays < 0 || n_arrays > kHashMax)
+        return fail(CARD_E_INVALID, "card_content_hash: bad argument (at most %d arrays)", kHashMax);
+    HashArgs h;
+    memset(&h, 0, sizeof(h));
+    long long total = 0;
+    for (int k = 0; k < n_arrays; ++k) {
+        if (n_words[k] < 0 || (n_words[k] > 0 && !arrays[k])) return fail(CARD_E_INVALID, "card_content_hash: array %d is null or negative-sized", k);
+        h.ptr[k] = (const uint32_t*)arrays[k];
+        h.count[k] = n_words[k];
+        total += n_words[k];
+    }
+    h.n = n_arrays;
+    HIP_TRY(hipMemsetAsync(out, 0, sizeof(uint64_t), (hipStream_t)stream));
+    if (total == 0) return CARD_OK;
+    long long grid = (total + 256 * 8 - 1) / (256 * 8);
+    if (grid > 2048) grid = 2048;
+    content_hash_kernel<<<dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream>>>(h, (unsigned long long*)out);
+    HIP_TRY(hipGetLastError());
+    return CARD_OK;
+}
+
 extern "C" CARD_API int card_eps_theta(const card_sampler* s, const float* x, const float* y_t, const float* y_0_hat,
                                        int64_t N, int32_t t, float* out, void* workspace, uint64_t workspace_bytes,
                                        void* stream) {
@@ -198,15 +246,14 @@ extern "C" CARD_API int card_eps_theta(const card_sampler* s, const float* x, co
 extern "C" CARD_API int card_q_sample(const float* y, const float* y_0_hat, const float* sab, const float* somab,
                              const int64_t* t, int64_t N, int32_t y_dim, int32_t T, const float* noise, uint64_t seed,
                              uint64_t elem_offset, float* out, void* stream) {
-    (void)T;
     if (!y || !y_0_hat || !sab || !somab || !t || !out) return fail(CARD_E_INVALID, "card_q_sample: null argument");
-    if (N < 0 || y_dim < 1) return fail(CARD_E_INVALID, "card_q_sample: bad N / y_dim");
+    if (N < 0 || y_dim < 1 || T < 1) return fail(CARD_E_INVALID, "card_q_sample: bad N / y_dim / T");
     if (N == 0) return CARD_OK;
     const long long n = (long long)N * y_dim;
     long long grid = (n + 255) / 256;
     if (grid > 4096) grid = 4096;
-    q_sample_kernel<<<dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream>>>(y, y_0_hat, sab, somab, t, n, y_dim, noise, seed,
-                                                                                  elem_offset, out);
+    q_sample_kernel<<<dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream>>>(y, y_0_hat, sab, somab, t, n, y_dim, T, noise,
+                                                                                  seed, elem_offset, out);
     HIP_TRY(hipGetLastError());
     return CARD_OK;
 }

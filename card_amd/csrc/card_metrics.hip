@@ -17,8 +17,9 @@ struct MetricParams {
     const float* y_true;    // (rows)  normalised targets
     long long rows;
     int n_z, n_pad, n_bins;
+    int trim_lo_i, trim_hi_i; // sorted-sample index window of the trimmed mean; lo == hi: median (trim range (50, 50))
     float y_scale, y_shift; // un-normalise: v * scale + shift
-    float trim_lo, trim_hi, picp_lo, picp_hi;
+    float picp_lo, picp_hi;
     float tau;              // > 0: global precision; <= 0: per-row 1 / var(samples, unbiased) of un-normalised samples
     float* se;              // (n_states, rows) squared error of the (trimmed) mean prediction, un-normalised
     float* nll;             // (n_states, rows)
@@ -102,16 +103,18 @@ __global__ __launch_bounds__(256) void row_metrics_kernel(const MetricParams p) 
             __syncthreads();
         }
     }
-    // trimmed mean prediction (card_regression.py:773-776)
-    const int lo_i = (int)(p.trim_lo / 100.0f * n), hi_i = (int)(p.trim_hi / 100.0f * n);
+    // prediction: trimmed mean of the sorted samples (card_regression.py:773-776), or their median when the trim range
+    // is (50, 50) (:770-771; np.median = mean of the two middle samples for even n) -- the host passes lo == hi then
+    const int lo_i = p.trim_lo_i, hi_i = p.trim_hi_i;
     double tm = 0.0;
     for (int i = lo_i + tid; i < hi_i; i += 256) tm += srt[i];
     red[tid] = tm; __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
     if (tid == 0) {
         const long long o = st * p.rows + row;
-        const double cnt = hi_i > lo_i ? (double)(hi_i - lo_i) : 1.0;
-        const double pred = (red[0] / cnt) * p.y_scale + p.y_shift;
+        const double center = hi_i > lo_i ? red[0] / (double)(hi_i - lo_i)
+                                          : ((n & 1) ? (double)srt[n / 2] : 0.5 * ((double)srt[n / 2 - 1] + (double)srt[n / 2]));
+        const double pred = center * p.y_scale + p.y_shift;
         p.se[o] = (float)((pred - yt) * (pred - yt));
         p.nll[o] = (float)(-(lse - log((double)n) - 0.5 * log(2.0 * 3.14159265358979323846) + 0.5 * log(tau)));
         int member = 0;
@@ -141,7 +144,18 @@ extern "C" CARD_API int card_regression_row_metrics(const card_metric_args* a, v
     while (P < a->n_z) P <<= 1;
     p.n_pad = P;
     p.y_scale = a->y_scale; p.y_shift = a->y_shift;
-    p.trim_lo = a->trim_lo; p.trim_hi = a->trim_hi; p.picp_lo = a->picp_lo; p.picp_hi = a->picp_hi; p.tau = a->tau;
+    // index window of the trimmed mean exactly as the reference forms it: int(low / 100 * n_z) (card_regression.py:774-775)
+    if (a->trim_lo == 50.0f && a->trim_hi == 50.0f) {
+        p.trim_lo_i = p.trim_hi_i = 0;                 // median
+    } else {
+        p.trim_lo_i = (int)((double)a->trim_lo / 100.0 * a->n_z);
+        p.trim_hi_i = (int)((double)a->trim_hi / 100.0 * a->n_z);
+        if (!(a->trim_lo >= 0.0f && a->trim_hi <= 100.0f) || p.trim_hi_i <= p.trim_lo_i)
+            return card_fail(CARD_E_INVALID, "card_regression_row_metrics: trimmed_mean_range (%g, %g) keeps no sample of n_z=%d "
+                             "(the reference would average an empty slice); only (50, 50) selects the median",
+                             (double)a->trim_lo, (double)a->trim_hi, a->n_z);
+    }
+    p.picp_lo = a->picp_lo; p.picp_hi = a->picp_hi; p.tau = a->tau;
     p.se = a->se; p.nll = a->nll; p.qice_bin = a->qice_bin; p.picp_in = a->picp_in;
     // gridDim.x is limited to 2^31-1 rows; rows beyond that would need chunking
     if (a->rows > 2147483647LL) return card_fail(CARD_E_UNSUPPORTED, "card_regression_row_metrics: too many rows");

@@ -9,6 +9,7 @@ Everything here runs on the GPU through libcard_hip.so.  No fallback.
 """
 import math
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -16,8 +17,10 @@ from ._lib import CardError
 from .sampler import (coef_on_device, make_coef_table, sampler_for, x_features, _dev_f32, _ptr, _stream,
                       _require_cuda)
 
-__all__ = ["make_beta_schedule", "extract", "q_sample", "p_sample", "p_sample_t_1to0", "p_sample_loop",
-           "p_sample_loop_with_eval", "y_0_reparam"]
+# every public name of regression/diffusion_utils.py and classification/diffusion_utils.py (the runners star-import the
+# module: regression/card_regression.py:16 uses kld at :685), plus this package's extras
+__all__ = ["make_beta_schedule", "extract", "q_sample", "p_sample", "p_sample_t_1to0", "p_sample_loop", "kld",
+           "y_0_reparam", "p_sample_loop_with_eval", "p_sample_loop_with_y"]
 
 
 def make_beta_schedule(schedule="linear", num_timesteps=1000, start=1e-5, end=1e-2):
@@ -70,9 +73,14 @@ def q_sample(y, y_0_hat, alphas_bar_sqrt, one_minus_alphas_bar_sqrt, t, noise=No
     if yy.dim() != 2 or y0.shape != yy.shape:
         raise CardError(f"q_sample: y {tuple(y.shape)} and y_0_hat {tuple(y_0_hat.shape)} must both be (N, y_dim)")
     sab, som = _dev_f32(alphas_bar_sqrt, device), _dev_f32(one_minus_alphas_bar_sqrt, device)
-    tt = t.detach().to(device=device, dtype=torch.int64).contiguous()
+    tt = t.detach().to(device=device, dtype=torch.int64).reshape(-1)
+    if tt.numel() == 1 and yy.shape[0] != 1:
+        tt = tt.expand(yy.shape[0])          # a shared timestep broadcasts like the reference's extract() (card_regression.py:512-514)
+    tt = tt.contiguous()
     if tt.numel() != yy.shape[0]:
-        raise CardError("q_sample: t must have one entry per row of y")
+        raise CardError("q_sample: t must have one entry per row of y (or a single shared entry)")
+    if tt.numel() and bool(((tt < 0) | (tt >= sab.numel())).any()):
+        raise CardError(f"q_sample: t outside [0, {sab.numel() - 1}] (torch.gather would raise in the reference)")
     nz = _dev_f32(noise, device) if noise is not None else None
     if nz is not None and nz.shape != yy.shape:
         raise CardError("q_sample: noise must have y's shape")
@@ -88,11 +96,12 @@ def q_sample(y, y_0_hat, alphas_bar_sqrt, one_minus_alphas_bar_sqrt, t, noise=No
 def p_sample(model, x, y, y_0_hat, y_T_mean, t, alphas, one_minus_alphas_bar_sqrt, *, noise=None, seed=None,
              elem_offset=0):
     """regression/diffusion_utils.py:57-90: one reverse step y_t -> y_{t-1}, t an int in [1, T-1]."""
-    s = sampler_for(model)
     T = int(alphas.shape[0])
     t = int(t)
     if not 1 <= t < T:
         raise CardError(f"p_sample: t={t} outside [1, {T - 1}]")
+    # weights are re-checked by content on the first step of a loop (see sampler.py), by identity on every step
+    s = sampler_for(model, check_content=(t == T - 1))
     coef = coef_on_device(alphas, one_minus_alphas_bar_sqrt, T, s.device)
     seed = _fresh_seed() if (seed is None and noise is None) else int(seed or 0)
     return s.run(_model_x(model, s, x), y_0_hat, y_T_mean, coef, T, t_hi=t, t_lo=t, y_init=y, noise=noise, seed=seed,
@@ -106,10 +115,26 @@ def _coef_row(one_minus_alphas_bar_sqrt, ti):
     return make_coef_table(torch.ones(1), som, 1)
 
 
+_row0_cache = {}
+
+
+def _coef_row0_on_device(omabs, device):
+    """Row 0 on the device, cached per schedule tensor object like coef_on_device (the entry holds the tensor)."""
+    key = (id(omabs), str(device))
+    hit = _row0_cache.get(key)
+    if hit is not None and hit[0] is omabs and hit[1] == omabs._version:
+        return hit[2]
+    if len(_row0_cache) > 16:
+        _row0_cache.clear()
+    row = _coef_row(omabs, 0).to(device)
+    _row0_cache[key] = (omabs, omabs._version, row)
+    return row
+
+
 def p_sample_t_1to0(model, x, y, y_0_hat, y_T_mean, one_minus_alphas_bar_sqrt):
     """regression/diffusion_utils.py:94-104: the last step (timestep index 0), no noise."""
-    s = sampler_for(model)
-    coef = _coef_row(one_minus_alphas_bar_sqrt, 0).to(s.device)
+    s = sampler_for(model, check_content=False)        # last step of a loop whose first step checked the weights
+    coef = _coef_row0_on_device(one_minus_alphas_bar_sqrt, s.device)
     return s.run(_model_x(model, s, x), y_0_hat, y_T_mean, coef, 1, t_hi=0, t_lo=0, y_init=y)
 
 
@@ -147,6 +172,30 @@ def p_sample_loop(model, x, y_0_hat, y_T_mean, n_steps, alphas, one_minus_alphas
     out = list(seq.unbind(0))
     assert len(out) == T + 1
     return out
+
+
+def p_sample_loop_with_y(model, x, y, y_0_hat, y_T_mean, T, alphas, one_minus_alphas_bar_sqrt, **kw):
+    """The 8-argument form BASELINE.json's north_star quotes, `p_sample_loop(model, x, y, y_0_hat, y_T_mean, T, alphas,
+    one_minus_alphas_bar_sqrt)`, as a thin adapter: the reference's own signature has no `y`
+    (regression/diffusion_utils.py:107) because the reverse process starts from noise around y_T_mean and never reads
+    the targets.  `y` is therefore only validated (None, or one row per chain / per test row) and otherwise unused."""
+    if y is not None:
+        n_z = max(1, int(kw.get("n_z", 1)))
+        rows = int(y_0_hat.shape[0])
+        if y.dim() != 2 or y.shape[1] != y_0_hat.shape[1] or int(y.shape[0]) not in (rows, rows * n_z):
+            raise CardError(f"p_sample_loop_with_y: y {tuple(y.shape)} does not match y_0_hat {tuple(y_0_hat.shape)}")
+    return p_sample_loop(model, x, y_0_hat, y_T_mean, T, alphas, one_minus_alphas_bar_sqrt, **kw)
+
+
+def kld(y1, y2, grid=(-20, 20), num_grid=400):
+    """regression/diffusion_utils.py:123-129: histogram KL divergence between two sample sets (CPU tensors), used by
+    Diffusion.sample's plots (regression/card_regression.py:685-736).  Host-side numpy like the reference: it is
+    evaluation glue on a few thousand samples, not part of the sampling path."""
+    y1, y2 = y1.numpy().flatten(), y2.numpy().flatten()
+    p1, _ = np.histogram(y1, bins=num_grid, range=[grid[0], grid[1]], density=True)
+    p2, _ = np.histogram(y2, bins=num_grid, range=[grid[0], grid[1]], density=True)
+    p1, p2 = p1 + 1e-7, p2 + 1e-7
+    return (p1 * np.log(p1 / p2)).sum()
 
 
 def p_sample_loop_with_eval(model, x, y_0_hat, y_T_mean, n_steps, alphas, one_minus_alphas_bar_sqrt, on_state,

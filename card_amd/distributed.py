@@ -41,15 +41,23 @@ def _default_sample_rows_fn(model, x_rows, y0_rows, mu_rows, n_z, n_steps, alpha
 
 def sharded_sample_y0(model, x_rows, y_0_hat_rows, y_T_mean_rows, n_z: int, n_steps: int, alphas, omabs, *,
                       seed: int, group=None, gather: bool = True,
-                      sample_fn: Optional[Callable] = None):
+                      sample_fn: Optional[Callable] = None, rank: Optional[int] = None, world: Optional[int] = None):
     """Sample y_0 for every (row, z) with rows sharded over the ranks of `group`.
 
     x_rows (R, x_dim), y_0_hat_rows / y_T_mean_rows (R, y_dim) are the FULL test set on every rank (they are
     small); each rank tiles and samples only its block.  Returns (y0_local (r_local, n_z, y_dim), (lo, hi)) and,
     when gather=True, instead the full (R, n_z, y_dim) tensor assembled on every rank with all_gather.
-    `sample_fn` lets tests substitute the sampler (signature of _default_sample_fn)."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    `sample_fn` lets tests substitute the sampler (signature of _default_sample_fn); `rank` / `world` override the
+    process group's (to sample one shard of a larger job from a single process; implies no collective)."""
+    emulated = rank is not None or world is not None
+    if emulated:
+        if rank is None or world is None:
+            raise ValueError("pass rank and world together")
+        if gather:
+            raise ValueError("an emulated shard (rank/world override) has no group to gather over: use gather=False")
+    else:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
     R, y_dim = y_0_hat_rows.shape
     lo, hi = row_shard(R, rank, world)
     if hi > lo:
@@ -64,8 +72,10 @@ def sharded_sample_y0(model, x_rows, y_0_hat_rows, y_T_mean_rows, n_z: int, n_st
         local = out.reshape(hi - lo, n_z, y_dim)
     else:
         local = y_0_hat_rows.new_zeros((0, n_z, y_dim))
-    if not gather or world == 1:
-        return (local, (lo, hi)) if not gather else local
+    if not gather:
+        return local, (lo, hi)
+    if not dist.is_initialized():
+        return local
     # all_gather needs equal shapes: pad every shard to the largest block, then trim
     r_max = -(-R // world)
     pad = local.new_zeros((r_max, n_z, y_dim))
@@ -75,39 +85,17 @@ def sharded_sample_y0(model, x_rows, y_0_hat_rows, y_T_mean_rows, n_z: int, n_st
     return torch.cat([parts[r][: row_shard(R, r, world)[1] - row_shard(R, r, world)[0]] for r in range(world)], 0)
 
 
-def regression_metric_sums(y0_local: torch.Tensor, y_true_local: torch.Tensor, n_bins: int = 10,
-                           picp_range=(2.5, 97.5)) -> torch.Tensor:
-    """Per-rank additive evaluation sums for y_dim = 1, the quantities the reference reduces over the test set:
-    [n_rows, sum squared error of the predictive mean (card_regression.py:776-783, trimmed range 0-100),
-     PICP in-range count (:818-821), QICE bin counts (n_bins + 2 entries, :788-796)].
-    y0_local: (rows, n_z, 1) samples, y_true_local: (rows, 1).  Percentiles use numpy's linear interpolation."""
-    rows = y0_local.shape[0]
-    out = torch.zeros(3 + n_bins + 2, dtype=torch.float64, device=y0_local.device)
-    if rows == 0:
-        return out
-    s = y0_local.reshape(rows, -1).double()
-    yt = y_true_local.reshape(rows, 1).double()
-    out[0] = rows
-    out[1] = ((s.mean(1, keepdim=True) - yt) ** 2).sum()
-    q = torch.tensor(picp_range, dtype=torch.float64, device=s.device) / 100
-    ci = torch.quantile(s, q, dim=1)                                   # linear interpolation, like np.percentile
-    out[2] = ((yt[:, 0] >= ci[0]) & (yt[:, 0] <= ci[1])).sum()
-    qs = torch.arange(n_bins + 1, dtype=torch.float64, device=s.device) / n_bins
-    quant = torch.quantile(s, qs, dim=1)                               # (n_bins+1, rows)
-    member = ((yt.T - quant) > 0).sum(0)                               # 0 .. n_bins+1
-    out[3:] = torch.bincount(member, minlength=n_bins + 2).double()
-    return out
-
-
-def finalize_regression_metrics(sums: torch.Tensor, n_bins: int = 10):
-    """RMSE, PICP, QICE from (all-reduced) sums; QICE folds the two outer bins like card_regression.py:803-810."""
-    n = float(sums[0])
-    counts = sums[3:].clone()
-    counts[1] += counts[0]
-    counts[-2] += counts[-1]
-    ratio = counts[1:-1] / n
-    return {"rmse": float((sums[1] / n).sqrt()), "picp": float(sums[2] / n),
-            "qice": float((1.0 / n_bins - ratio).abs().mean()), "n": int(n)}
+def sharded_regression_metrics(y0_local: torch.Tensor, y_true_local: torch.Tensor, *, n_bins: int = 10, group=None,
+                               sums_fn: Optional[Callable] = None, **kw):
+    """RMSE / PICP / NLL / QICE over the whole (sharded) test set: this rank's additive sums from the HIP metrics kernel
+    (card_amd.metrics.regression_metric_sums: [n, sum SE, PICP count, sum NLL, QICE bin counts])
+    followed by ONE all-reduce of that short vector -- the only collective of the evaluation.
+    y0_local: (rows_local, n_z, 1) samples of this rank's rows; y_true_local: (rows_local, 1).  `sums_fn` lets CPU
+    tests substitute the kernel.  Returns (metrics dict, all-reduced sums)."""
+    from . import metrics
+    fn = metrics.regression_metric_sums if sums_fn is None else sums_fn
+    sums = all_reduce_sums(fn(y0_local, y_true_local, n_bins=n_bins, **kw), group=group)
+    return metrics.finalize(sums, n_bins), sums
 
 
 def all_reduce_sums(sums: torch.Tensor, group=None) -> torch.Tensor:

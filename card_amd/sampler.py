@@ -45,14 +45,19 @@ _coef_cache = {}
 
 
 def coef_on_device(alphas, omabs, T, device):
-    key = (alphas.data_ptr(), alphas._version, omabs.data_ptr(), omabs._version, int(T), str(device))
+    """The (T, 8) coefficient table of a schedule on `device`, cached per schedule TENSOR OBJECT (the runner keeps
+    `self.alphas` / `self.one_minus_alphas_bar_sqrt` for its lifetime, regression/card_regression.py:42-48).  An entry
+    holds the two tensors it was computed from, so their ids / addresses cannot be recycled while it lives; a fresh
+    tensor (even with equal values at a reused address) is a miss and gets its own table."""
+    key = (id(alphas), id(omabs), int(T), str(device))
     hit = _coef_cache.get(key)
-    if hit is None:
-        if len(_coef_cache) > 16:
-            _coef_cache.clear()
-        hit = make_coef_table(alphas, omabs, T).to(device)
-        _coef_cache[key] = hit
-    return hit
+    if hit is not None and hit[0] is alphas and hit[1] is omabs and hit[2] == (alphas._version, omabs._version):
+        return hit[3]
+    if len(_coef_cache) > 16:
+        _coef_cache.clear()
+    tab = make_coef_table(alphas, omabs, T).to(device)
+    _coef_cache[key] = (alphas, omabs, (alphas._version, omabs._version), tab)
+    return tab
 
 
 class Sampler:
@@ -92,6 +97,8 @@ class Sampler:
             # stream-ordered, so releasing them after this point is safe
         self._h = h
         self.workspace_limit = None      # bytes; set to bound the GEMM back end's workspace (runs then go in chunks)
+        self._ws = None                  # (tensor, aligned ptr, bytes): grown on demand, reused by later calls
+        self._slot_cache = {}            # CARD_OUT_SELECT state -> slot tables on the device
         self._destroy = L.card_sampler_destroy
         weakref.finalize(self, L.card_sampler_destroy, h)
 
@@ -149,15 +156,19 @@ class Sampler:
         if nb.value == 0:
             return None, C.c_void_p(0), 0
         nbytes = nb.value if self.workspace_limit is None else min(nb.value, int(self.workspace_limit))
-        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
-        ptr = (ws.data_ptr() + 255) & ~255
-        return ws, C.c_void_p(ptr), nbytes
+        # one buffer per sampler, kept between calls (calls on one sampler must not overlap anyway, card_hip.h) and
+        # replaced only when a call needs more: the reference's per-timestep p_sample calls then allocate nothing
+        if self._ws is None or self._ws[2] < nbytes or (self.workspace_limit is not None and self._ws[2] > nbytes):
+            ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+            self._ws = (ws, C.c_void_p((ws.data_ptr() + 255) & ~255), nbytes)
+        return self._ws[0], self._ws[1], nbytes
 
     # ------------------------------------------------------------------------------------------
     def _prep(self, t, cols, name):
         if t is None:
             return None
-        t = _dev_f32(t, self.device)
+        if not (t.dtype is torch.float32 and t.device == self.device and t.is_contiguous() and not t.requires_grad):
+            t = _dev_f32(t, self.device)
         if t.dim() != 2 or t.shape[1] != cols:
             raise CardError(f"{name}: expected shape (N, {cols}), got {tuple(t.shape)}")
         return t
@@ -195,13 +206,25 @@ class Sampler:
         elif out_mode == _lib.OUT_ALL:
             out = torch.empty(n_states, N, self.y_dim, device=self.device, dtype=torch.float32)
         else:
-            states = [int(s) for s in states]
-            table = torch.full((T + 1,), -1, dtype=torch.int32)
-            for i, s in enumerate(states):
-                if not 0 <= s <= T:
-                    raise CardError(f"state index {s} outside [0, {T}]")
-                table[s] = i
-            slot = table.to(self.device)
+            states = tuple(int(s) for s in states)
+            # states this call produces: s = T - t for the processed timesteps, plus y_T (s = 0) when the loop starts here
+            first = T - t_hi - (0 if yi is not None else 1)
+            slot = self._slot_cache.get((T, states))
+            if slot is None:
+                if len(set(states)) != len(states):
+                    raise CardError(f"states {list(states)} lists a state twice (each output slot is written once)")
+                table = torch.full((T + 1,), -1, dtype=torch.int32)
+                for i, s in enumerate(states):
+                    if not 0 <= s <= T:
+                        raise CardError(f"state index {s} outside [0, {T}]")
+                    table[s] = i
+                if len(self._slot_cache) > 64:
+                    self._slot_cache.clear()
+                slot = self._slot_cache[(T, states)] = table.to(self.device)
+            bad = [s for s in states if not first <= s <= T - t_lo]
+            if bad:
+                raise CardError(f"states {bad} are not produced by timesteps {t_hi}..{t_lo} of T={T} "
+                                f"(this call produces states {first}..{T - t_lo}); their slots would stay unwritten")
             out = torch.empty(len(states), N, self.y_dim, device=self.device, dtype=torch.float32)
         a = _lib.RunArgs()
         a.struct_bytes = C.sizeof(_lib.RunArgs)
@@ -210,9 +233,14 @@ class Sampler:
         a.coef, a.noise = _ptr(coef), _ptr(nz)
         a.seed, a.elem_offset = int(seed) & (2 ** 64 - 1), int(elem_offset)
         a.out, a.out_mode, a.state_slot, a.n_z = _ptr(out), out_mode, _ptr(slot), n_z
+        L = _lib.lib()
+        fn, what = L.card_sampler_run, "card_sampler_run"
         ws, a.workspace, a.workspace_bytes = self._workspace(N)
-        with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().card_sampler_run(self._h, C.byref(a), _stream(self.device)), "card_sampler_run")
+        if torch.cuda.current_device() == self.device.index:
+            _lib.check(fn(self._h, C.byref(a), _stream(self.device)), what)
+        else:
+            with torch.cuda.device(self.device):
+                _lib.check(fn(self._h, C.byref(a), _stream(self.device)), what)
         return out
 
     def eps_theta(self, x, y_t, y_0_hat, t):
@@ -231,14 +259,54 @@ class Sampler:
 
 
 # ------------------------------------------------------------------------------------------------
-# model -> Sampler, cached per model object and invalidated when any parameter is modified in place
-# (the reference copies the EMA shadow into the parameters before testing: regression/card_regression.py:934-940)
+# model -> Sampler, cached per model object.  A cached sampler is reused only while the model's weights are what it
+# was packed from.  Two checks:
+#   * identity key: (id, data_ptr, _version) of every parameter and buffer -- catches optimizer steps, load_state_dict,
+#     in-place ops on the parameters, replaced parameter objects.  Cheap (no device work), evaluated on every call.
+#   * content hash: card_content_hash over the same tensors (one launch + one 8-byte read-back) -- catches what PyTorch's
+#     version counters do not see, notably the reference's own EMA copy `param.data.copy_(shadow)` (regression/ema.py:21,
+#     applied before testing at regression/card_regression.py:934-940).  Evaluated at every whole-loop entry
+#     (p_sample_loop, p_sample_loop_with_eval) and, for the per-timestep entry points, on the first step of a loop
+#     (t = T-1, where `for t in reversed(range(1, T))` starts) -- a model edited through `.data` BETWEEN two p_sample
+#     calls of one loop is the one case left to `invalidate(model)`.
 # ------------------------------------------------------------------------------------------------
 _cache = weakref.WeakKeyDictionary()
 
 
+def _tensors(model):
+    import itertools
+    return list(itertools.chain(model.parameters(), model.buffers()))
+
+
 def _fingerprint(model):
-    return tuple((p.data_ptr(), p._version, str(p.device)) for p in model.state_dict().values())
+    return tuple((id(p), p.data_ptr(), p._version) for p in _tensors(model))
+
+
+def _content_hash(model):
+    """card_content_hash of every parameter and buffer (device-side, one launch; reads back 8 bytes)."""
+    ts = [p.detach() for p in _tensors(model) if p.numel() > 0]
+    ts = [t if t.is_contiguous() else t.contiguous() for t in ts]
+    if not ts or ts[0].device.type != "cuda":
+        return 0
+    dev = ts[0].device
+    n = len(ts)
+    L = _lib.lib()
+    out = torch.empty(1, dtype=torch.int64, device=dev)
+    total = 0
+    with torch.cuda.device(dev):
+        for lo in range(0, n, 32):                      # the entry point takes at most 32 arrays per call
+            part = ts[lo:lo + 32]
+            ptrs = (C.c_void_p * len(part))(*[t.data_ptr() for t in part])
+            words = (C.c_int64 * len(part))(*[t.numel() * t.element_size() // 4 for t in part])
+            _lib.check(L.card_content_hash(ptrs, words, len(part), _ptr(out), _stream(dev)), "card_content_hash")
+            total = (total * 1000003 + int(out.item())) & (2 ** 64 - 1)
+    return total
+
+
+def invalidate(model):
+    """Forget the packed sampler (and hoisted features) of `model`: the next call re-packs from the current weights."""
+    _cache.pop(model, None)
+    _xfeat_cache.pop(model, None)
 
 
 def _is_guided(model):
@@ -265,31 +333,49 @@ def _imagenet_theta(model):
 
 def x_features(model, x):
     """x_feat = norm(encoder_x(x)) (classification/model.py:80-81) or linx(z) (imagenet/card/builder.py:90), computed
-    ONCE per distinct x tensor instead of once per timestep: in eval mode it does not depend on t or y.
+    ONCE per x tensor object instead of once per timestep: in eval mode it does not depend on t or y.  The cache entry
+    is tied to the x OBJECT through a weak reference (an address alone can be recycled by the caching allocator for the
+    next batch) and dies with it, so the features are not pinned beyond the caller's own x.
     Stock PyTorch-ROCm (out of scope to fuse)."""
-    key = (x.data_ptr(), x._version, tuple(x.shape), str(x.device)) + _fingerprint(model)
     hit = _xfeat_cache.get(model)
-    if hit is not None and hit[0] == key:
-        return hit[1]
+    if hit is not None and hit[0]() is x and hit[1] == (x._version, _cache.get(model, (None,))[0]):
+        return hit[2]
     theta = _imagenet_theta(model)
     with torch.no_grad():
         xf = (theta.linx(x) if theta is not None else model.norm(model.encoder_x(x))).float().contiguous()
-    _xfeat_cache[model] = (key, xf)
+    mref = weakref.ref(model)
+
+    def _drop(_, mref=mref):
+        m = mref()
+        if m is not None:
+            _xfeat_cache.pop(m, None)
+
+    _xfeat_cache[model] = (weakref.ref(x, _drop), (x._version, _cache.get(model, (None,))[0]), xf)
     return xf
 
 
-def sampler_for(model):
-    """The cached Sampler of an eps_theta `nn.Module` (raises for architectures the kernels do not cover)."""
-    if getattr(model, "training", False):
-        raise CardError("card_amd samples in eval mode only (call model.eval(); the reference tests under "
-                        "model.eval() + torch.no_grad(), regression/card_regression.py:944, :1006)")
+def sampler_for(model, check_content=True):
+    """The cached Sampler of an eps_theta `nn.Module` (raises for architectures the kernels do not cover).
+    check_content=False skips the content hash (per-timestep callers inside one loop)."""
+    if getattr(model, "training", False) and hasattr(model, "unetnorm1"):
+        raise CardError("card_amd samples a BatchNorm model in eval mode only: in train mode BatchNorm normalises with "
+                        "batch statistics and the folded (scale, shift) would be wrong (call model.eval(); the "
+                        "reference tests under model.eval(), classification/card_classification.py:873)")
     fp = _fingerprint(model)
     hit = _cache.get(model)
     if hit is not None and hit[0] == fp:
-        return hit[1]
+        if not check_content:
+            return hit[1]
+        h = _content_hash(model)
+        if h == hit[2]:
+            return hit[1]
+    else:
+        h = None
     device = next(model.parameters()).device
     _require_cuda(device)
     if _is_guided(model):
+        # no train/eval-dependent layer in regression/model.py:21-51: the reference samples from it in train mode too
+        # (validation inside train(), regression/card_regression.py:365 -> :457, :533)
         s = Sampler.from_state_dict(model.state_dict(), cat_x=bool(model.cat_x), cat_y_pred=bool(model.cat_y_pred),
                                     device=device)
     elif _imagenet_theta(model) is not None:
@@ -303,5 +389,6 @@ def sampler_for(model):
         raise CardError(f"card_amd does not recognise {type(model).__name__} as a CARD eps_theta network "
                         "(expected regression ConditionalGuidedModel, classification ConditionalModel or the ImageNet head); "
                         "there is no eager fallback")
-    _cache[model] = (fp, s)
+    _cache[model] = (fp, s, _content_hash(model) if h is None else h)
+    _xfeat_cache.pop(model, None)
     return s

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CARD_HIP_VERSION 100 /* major*10000 + minor*100 + patch */
+#define CARD_HIP_VERSION 200 /* major*10000 + minor*100 + patch */
 #define CARD_API __attribute__((visibility("default")))
 
 typedef enum card_status {
@@ -155,6 +155,12 @@ typedef struct card_run_args {
  * p_sample_t_1to0 (:94-104) with t_hi = t_lo = 0. */
 CARD_API int card_sampler_run(const card_sampler* s, const card_run_args* args, void* stream);
 
+/* 64-bit position-weighted checksum of n_arrays device arrays of 32-bit words (n_words[k] words each), written to the
+ * device word *out on `stream`.  No reference counterpart: the Python binding uses it to notice weights that were
+ * modified in place behind PyTorch's version counters (the reference's EMA copy, regression/ema.py:21, is
+ * `param.data.copy_`) and re-pack the sampler.  arrays / n_words are host arrays; at most 32 arrays. */
+CARD_API int card_content_hash(const void* const* arrays, const int64_t* n_words, int32_t n_arrays, uint64_t* out, void* stream);
+
 /* Scratch bytes that suffice for card_sampler_run / card_eps_theta on N chains: 0 for samplers on the persistent
  * kernels; on the GEMM back end the activations of min(N, about 4 GiB worth of) chains -- larger batches run in
  * chunks, so the figure stops growing with N.  No reference counterpart: the reference lets PyTorch allocate its
@@ -192,7 +198,9 @@ typedef struct card_metric_args {
     const float* samples;   /* device (n_states, rows, n_z): chain order (row, z) of the sampler output */
     const float* y_true;    /* device (rows): normalised targets */
     float y_scale, y_shift; /* un-normalise v -> v*scale + shift for SE and NLL (scaler_y.inverse_transform); 1, 0 if none */
-    float trim_lo, trim_hi; /* config.testing.trimmed_mean_range in percent (0, 100) */
+    float trim_lo, trim_hi; /* config.testing.trimmed_mean_range in percent: mean of sorted samples [int(lo/100*n_z), int(hi/100*n_z))
+                               (regression/card_regression.py:773-776); (50, 50) = the median (:770-771); any other range
+                               that keeps no sample is CARD_E_INVALID */
     float picp_lo, picp_hi; /* config.testing.PICP_range in percent (2.5, 97.5) */
     float tau;              /* > 0: global precision (set_NLL_global_precision); <= 0: per-row 1/var of the samples */
     float* se;              /* out (n_states, rows): squared error of the trimmed-mean prediction */

@@ -265,27 +265,156 @@ def gen_schedules(reg_du):
     print("schedules:", len(out) // 3)
 
 
+def gen_classification_synth(cls_du, cls_model, name, dataset, data_dim, C, Fdim, T, N, seed):
+    """Wide heads (CIFAR-10 width F = 4096, classification/configs/cifar10.yml:15-19; a 100-class head): the reference
+    ConditionalModel carries the theta weights of card_amd.synth.cls_state_dict(F, C, T, seed), which the GPU test
+    regenerates from the seed, so the fixture holds the seed, the inputs (x_feat = the reference's own
+    norm(encoder_x(x)), y_0_hat, noise) and the reference's outputs only -- not 2 x 64 MB of weights."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from card_amd.synth import cls_state_dict
+    torch.manual_seed(seed)
+    cfg = NS(diffusion=NS(timesteps=T),
+             model=NS(data_dim=data_dim, arch="linear", feature_dim=Fdim, hidden_dim=Fdim),
+             data=NS(num_classes=C, dataset=dataset))
+    model = cls_model.ConditionalModel(cfg, guidance=True)
+    missing, unexpected = model.load_state_dict(cls_state_dict(Fdim, C, T, seed), strict=False)
+    assert not unexpected and all(k.startswith(("encoder_x", "norm.")) for k in missing), (missing, unexpected)
+    model.eval()
+    alphas, abs_, omabs = schedule(cls_du, "linear", T, 1e-4, 0.1)     # random weights: a schedule that keeps |y| = O(10)
+    x = torch.randn(N, data_dim)
+    y0hat = torch.softmax(torch.randn(N, C) * 2, dim=1)
+    with torch.no_grad():
+        x_feat = model.norm(model.encoder_x(x))
+    noise, seq = run_loop(cls_du, model, x, y0hat, y0hat, T, alphas, omabs, seed + 1)
+    traj = torch.stack(seq, 0)
+    assert torch.equal(seq[0], noise[0] + y0hat)
+    probes = {}
+    with torch.no_grad():
+        for t in (T - 1, T // 2, 1):
+            probes[f"eps.t{t}"] = model(x, traj[T - t], torch.tensor([t]), y0hat).numpy()
+    np.savez(os.path.join(OUT, name + ".npz"), kind="classification_synth", T=T, seed=seed, F=Fdim, C=C,
+             x_feat=x_feat.numpy(), y0hat=y0hat.numpy(), yTmean=y0hat.numpy(), alphas=alphas.numpy(),
+             alphas_bar_sqrt=abs_.numpy(), omabs=omabs.numpy(), noise=noise.numpy(), traj_idx=np.arange(T + 1),
+             traj=traj.numpy(), probe_t=np.asarray([T - 1, T // 2, 1]), **probes)
+    print(f"{name}: N={N} T={T} C={C} F={Fdim} max|y|={traj.abs().max():.3f}")
+
+
+def reference_metric_closures(tau):
+    """The metric helpers are closures inside Diffusion.test (regression/card_regression.py:763-825, :866-893): pull
+    their FunctionDef nodes out of the reference source with `ast`, re-home them in a factory `make(self)` (they read
+    `self.tau`) and compile that -- the reference's own code runs, unedited, without importing the whole runner."""
+    import ast
+    import logging
+    from scipy.special import logsumexp
+    path = f"{REF}/regression/card_regression.py"
+    tree = ast.parse(open(path).read(), path)
+    want = ["compute_prediction_SE", "compute_true_coverage_by_gen_QI", "compute_PICP", "compute_batch_NLL"]
+    test_fn = next(n for c in tree.body if isinstance(c, ast.ClassDef) and c.name == "Diffusion"
+                   for n in c.body if isinstance(n, ast.FunctionDef) and n.name == "test")
+    found = [n for n in test_fn.body if isinstance(n, ast.FunctionDef) and n.name in want]
+    assert [n.name for n in found] == want
+    ret = ast.Return(ast.Dict([ast.Constant(n) for n in want], [ast.Name(n, ast.Load()) for n in want]))
+    args = ast.arguments(posonlyargs=[], args=[ast.arg("self")], kwonlyargs=[], kw_defaults=[], defaults=[])
+    make = ast.FunctionDef("make", args, found + [ret], [], type_params=[]) if sys.version_info >= (3, 12) else \
+        ast.FunctionDef("make", args, found + [ret], [])
+    mod = ast.fix_missing_locations(ast.Module([make], []))
+    ns = {"np": np, "torch": torch, "logsumexp": logsumexp, "logging": logging}
+    exec(compile(mod, path, "exec"), ns)
+    return ns["make"](NS(tau=tau))
+
+
+def gen_metrics(name, rows, n_z, seed, *, scaler, tau, trim, n_bins=10, picp=(2.5, 97.5)):
+    """Reference metric helpers on seeded samples -> tests/golden/metrics_*.npz (inputs + the reference's outputs)."""
+    from sklearn.preprocessing import StandardScaler
+    rng = np.random.default_rng(seed)
+    loc = rng.normal(size=(rows, 1, 1))
+    gen = (loc + rng.normal(size=(rows, n_z, 1)) * rng.uniform(0.2, 2.0, size=(rows, 1, 1))).astype(np.float32)
+    y = (loc[:, 0] + rng.normal(size=(rows, 1)) * 1.5).astype(np.float32)
+    ds = NS(normalize_y=scaler, test_n_samples=rows)
+    scale, shift = 1.0, 0.0
+    if scaler:
+        ds.scaler_y = StandardScaler().fit((rng.normal(size=(500, 1)) * 9.2 + 22.5).astype(np.float32))
+        scale, shift = float(ds.scaler_y.scale_[0]), float(ds.scaler_y.mean_[0])
+    cfg = NS(testing=NS(trimmed_mean_range=list(trim), n_z_samples=n_z, n_bins=n_bins, PICP_range=list(picp)),
+             model=NS(y_dim=1))
+    f = reference_metric_closures(tau)
+    yb = torch.from_numpy(y)
+    se = f["compute_prediction_SE"](cfg, ds, yb, gen.copy())          # sorts its argument in place
+    nll = f["compute_batch_NLL"](cfg, ds, yb, gen.copy())
+    ratio, qice, y_true_T = f["compute_true_coverage_by_gen_QI"](cfg, ds, y, gen.copy(), verbose=False)
+    cover, _, _, = f["compute_PICP"](cfg, y_true_T, gen.copy())
+    np.savez(os.path.join(OUT, name + ".npz"), kind="metrics", rows=rows, n_z=n_z, n_bins=n_bins, picp=np.asarray(picp),
+             trim=np.asarray(trim, dtype=np.float64), tau=np.float64(-1.0 if tau is None else tau), y_scale=scale,
+             y_shift=shift, gen=gen, y=y, se=np.asarray(se, dtype=np.float64).reshape(-1),
+             nll=np.asarray(nll, dtype=np.float64).reshape(-1), ratio_by_bin=np.asarray(ratio, dtype=np.float64),
+             qice=np.float64(qice), picp_coverage=np.float64(cover))
+    print(f"{name}: rows={rows} n_z={n_z} rmse={np.sqrt(np.mean(se)):.4f} nll={np.mean(nll):.4f} qice={qice:.4f} picp={cover:.4f}")
+
+
+def gen_fphi(reg_model, name, x_dim, N, seed):
+    """regression/model.py:55-82 DeterministicFeedForwardNeuralNetwork (the guidance net f_phi of the UCI configs:
+    hidden 100, 50, LeakyReLU 0.01, no batch norm, dropout 0.2 = identity in eval mode: regression/configs/uci_boston.yml:31-39)."""
+    torch.manual_seed(seed)
+    net = reg_model.DeterministicFeedForwardNeuralNetwork(dim_in=x_dim, dim_out=1, hid_layers=[100, 50],
+                                                          use_batchnorm=False, negative_slope=0.01,
+                                                          dropout_rate=0.2).eval()
+    x = torch.randn(N, x_dim)
+    with torch.no_grad():
+        y = net(x)
+    np.savez(os.path.join(OUT, name + ".npz"), kind="fphi", x=x.numpy(), y=y.numpy(), negative_slope=0.01,
+             **sd_arrays(net))
+    print(f"{name}: N={N} x_dim={x_dim} keys={list(net.state_dict())}")
+
+
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None, help="fixture names to (re)generate; default: all")
+    only = ap.parse_args().only
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
     reg_du, reg_model, cls_du, cls_model = load_reference()
-    gen_schedules(reg_du)
-    # T=50, beta 1e-4..0.4 is regression/configs/toy_loglog_cubic_regression.yml:32-34
-    gen_regression(reg_du, reg_model, "reg_toy_T50", 1, 50, ("linear", 50, 1e-4, 0.4), 48, 11, train_steps=3000)
-    gen_regression(reg_du, reg_model, "reg_boston_T50", 13, 50, ("linear", 50, 1e-4, 0.4), 40, 12, train_steps=3000)
-    gen_regression(reg_du, reg_model, "reg_year_T50", 90, 50, ("linear", 50, 1e-4, 0.4), 33, 13, train_steps=3000)
-    gen_regression(reg_du, reg_model, "reg_boston_rand_T50", 13, 50, ("linear", 50, 1e-4, 0.4), 40, 18)
-    gen_regression(reg_du, reg_model, "reg_nocatx_T50", 5, 50, ("linear", 50, 1e-4, 0.4), 16, 14, cat_x=False)
-    gen_regression(reg_du, reg_model, "reg_nocaty_T50", 5, 50, ("linear", 50, 1e-4, 0.4), 16, 15, cat_y_pred=False)
-    gen_regression(reg_du, reg_model, "reg_yonly_T50", 5, 50, ("linear", 50, 1e-4, 0.4), 16, 16,
-                   cat_x=False, cat_y_pred=False)
-    # T=1000, beta 1e-4..0.02 is regression/configs/uci_boston.yml:24-27; keep every 50th step
-    gen_regression(reg_du, reg_model, "reg_boston_T1000", 13, 1000, ("linear", 1000, 1e-4, 0.02), 32, 17,
-                   keep_every=50, train_steps=4000)
-    gen_classification(cls_du, cls_model, "cls_gaussmix_T50", "toy", 1, 3, 128, 50, 24, 21)
-    gen_classification(cls_du, cls_model, "cls_mnist_T50", "MNIST", 784, 10, 128, 50, 20, 22)
-    inet_du, inet_builder = load_imagenet_reference()
-    gen_imagenet_head(inet_du, inet_builder, "inet_head_T10", 20, 128, 10, 24, 31)
+    inet = []
+
+    def job(name, fn, *a, **k):
+        if only is None or name in only:
+            fn(*a, **k)
+
+    def inet_job(name, *a):
+        if only is None or name in only:
+            if not inet:
+                inet.extend(load_imagenet_reference())
+            gen_imagenet_head(inet[0], inet[1], name, *a)
+
+    job("schedules", gen_schedules, reg_du)
+    R = lambda name, *a, **k: job(name, gen_regression, reg_du, reg_model, name, *a, **k)
+    T50 = ("linear", 50, 1e-4, 0.4)          # regression/configs/toy_loglog_cubic_regression.yml:32-34
+    T1000 = ("linear", 1000, 1e-4, 0.02)     # regression/configs/uci_boston.yml:24-27; every 50th state is kept
+    R("reg_toy_T50", 1, 50, T50, 48, 11, train_steps=3000)
+    R("reg_boston_T50", 13, 50, T50, 40, 12, train_steps=3000)
+    R("reg_year_T50", 90, 50, T50, 33, 13, train_steps=3000)
+    R("reg_boston_rand_T50", 13, 50, T50, 40, 18)
+    R("reg_nocatx_T50", 5, 50, T50, 16, 14, cat_x=False)
+    R("reg_nocaty_T50", 5, 50, T50, 16, 15, cat_y_pred=False)
+    R("reg_yonly_T50", 5, 50, T50, 16, 16, cat_x=False, cat_y_pred=False)
+    R("reg_boston_T1000", 13, 1000, T1000, 32, 17, keep_every=50, train_steps=4000)
+    R("reg_toy_T1000", 1, 1000, T1000, 32, 19, keep_every=50, train_steps=4000)      # BASELINE configs[1] shape, d_in = 3
+    R("reg_year_T1000", 90, 1000, T1000, 32, 20, keep_every=50, train_steps=4000)    # BASELINE configs[2] shape, d_in = 92
+    K = lambda name, *a: job(name, gen_classification, cls_du, cls_model, name, *a)
+    K("cls_gaussmix_T50", "toy", 1, 3, 128, 50, 24, 21)
+    K("cls_mnist_T50", "MNIST", 784, 10, 128, 50, 20, 22)
+    S = lambda name, *a: job(name, gen_classification_synth, cls_du, cls_model, name, *a)
+    S("clsw_cifar10_T50", "CIFAR10", 3072, 10, 4096, 50, 24, 23)       # classification/configs/cifar10.yml:15-19
+    S("clsw_c100_T50", "CIFAR100", 64, 100, 256, 50, 24, 24)
+    inet_job("inet_head_T10", 20, 128, 10, 24, 31)
+    M = lambda name, *a, **k: job(name, gen_metrics, name, *a, **k)
+    M("metrics_nz1000_global_tau", 97, 1000, 1, scaler=True, tau=0.37, trim=(0, 100))
+    M("metrics_nz100_row_tau", 97, 100, 2, scaler=True, tau=None, trim=(0, 100))
+    M("metrics_nz257_trim", 97, 257, 3, scaler=False, tau=1.0, trim=(10, 90))
+    M("metrics_nz2", 97, 2, 4, scaler=True, tau=None, trim=(0, 100))
+    M("metrics_nz100_median", 97, 100, 5, scaler=True, tau=0.5, trim=(50, 50))
+    M("metrics_nz257_median", 97, 257, 6, scaler=False, tau=None, trim=(50, 50))
+    job("fphi_boston", gen_fphi, reg_model, "fphi_boston", 13, 64, 41)
+    job("fphi_year", gen_fphi, reg_model, "fphi_year", 90, 64, 42)
 
 
 if __name__ == "__main__":

@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for n in names:
         assert hasattr(L, n), n
-    assert _lib.lib().card_version() == 100
+    assert _lib.lib().card_version() == 200
 
 
 def test_struct_sizes_match_header_layout(tmp_path):

@@ -13,7 +13,8 @@ import torch.multiprocessing as mp
 
 from card_amd import distributed as cd
 from oracle import card_oracle as orc
-from tests.helpers import load_golden
+from card_amd import metrics
+from tests.helpers import cpu_metric_sums, load_golden
 
 N_Z, ROWS = 8, 7
 
@@ -36,7 +37,7 @@ def _worker(rank, world, port, q):
     local, (lo, hi) = cd.sharded_sample_y0(None, x, y0, y0, N_Z, g["T"], g["alphas"], g["omabs"], seed=77,
                                            gather=False, sample_fn=_oracle_sampler(g["weights"]))
     y_true = y0 + 0.3
-    sums = cd.all_reduce_sums(cd.regression_metric_sums(local, y_true[lo:hi]))
+    fin, sums = cd.sharded_regression_metrics(local, y_true[lo:hi], sums_fn=cpu_metric_sums)
     q.put((rank, full.numpy(), sums.numpy(), (lo, hi)))
     dist.barrier()
     dist.destroy_process_group()
@@ -64,7 +65,7 @@ def test_two_ranks_equal_one_rank():
     single = cd.sharded_sample_y0(None, x, y0, y0, N_Z, g["T"], g["alphas"], g["omabs"], seed=77,
                                   sample_fn=_oracle_sampler(g["weights"]))
     assert single.shape == (ROWS, N_Z, 1)
-    single_sums = cd.regression_metric_sums(single, y0 + 0.3)
+    single_sums = cpu_metric_sums(single, y0 + 0.3)
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -80,26 +81,22 @@ def test_two_ranks_equal_one_rank():
     for rank, full, sums, _ in res:
         assert np.array_equal(full, single.numpy())           # samples do not depend on the rank count
         np.testing.assert_allclose(sums, single_sums.numpy(), rtol=1e-12)
-    m = cd.finalize_regression_metrics(torch.from_numpy(res[0][2]))
-    assert m["n"] == ROWS and 0 <= m["picp"] <= 1 and 0 <= m["qice"] <= 1
+    m = metrics.finalize(torch.from_numpy(res[0][2]))
+    assert res[0][2][0, 0] == ROWS and 0 <= float(m["picp"][0]) <= 1 and 0 <= float(m["qice"][0]) <= 1
+    one = metrics.finalize(single_sums)
+    for k in ("rmse", "picp", "nll", "qice"):
+        assert abs(float(m[k][0]) - float(one[k][0])) < 1e-9, k
 
 
-def test_metric_sums_match_numpy_reference_formulas():
-    """QICE / PICP / SE sums against a numpy restatement of regression/card_regression.py:776-821."""
-    rng = np.random.default_rng(0)
-    rows, nz, n_bins = 40, 200, 10
-    gen = rng.normal(size=(rows, nz, 1)).astype(np.float32)
-    y = rng.normal(size=(rows, 1)).astype(np.float32)
-    sums = cd.regression_metric_sums(torch.from_numpy(gen), torch.from_numpy(y), n_bins).numpy()
-    quant = np.percentile(gen.squeeze(), q=np.arange(n_bins + 1) * (100 / n_bins), axis=1)
-    member = ((y.T - quant) > 0).astype(int).sum(axis=0)
-    counts = np.array([(member == v).sum() for v in np.arange(n_bins + 2)])
-    ci = np.percentile(gen.squeeze(), q=[2.5, 97.5], axis=1)
-    picp = ((y.T >= ci[0]) & (y.T <= ci[1])).sum()
-    se = ((gen.mean(axis=1) - y) ** 2).sum()
-    assert sums[0] == rows and np.array_equal(sums[3:], counts) and sums[2] == picp
-    np.testing.assert_allclose(sums[1], se, rtol=1e-5)
-    m = cd.finalize_regression_metrics(torch.from_numpy(sums), n_bins)
-    counts[1] += counts[0]; counts[-2] += counts[-1]
-    qice = np.absolute(np.ones(n_bins) / n_bins - counts[1:-1] / rows).mean()
-    assert abs(m["qice"] - qice) < 1e-12 and abs(m["picp"] - picp / rows) < 1e-12
+def test_emulated_shards_concatenate_to_the_whole():
+    """rank / world overrides: one process samples shard r of w without a process group; the blocks tile the whole."""
+    g = load_golden("reg_boston_T50")
+    x, y0 = g["x"][:ROWS], g["y0hat"][:ROWS]
+    fn = _oracle_sampler(g["weights"])
+    whole = cd.sharded_sample_y0(None, x, y0, y0, N_Z, g["T"], g["alphas"], g["omabs"], seed=5, sample_fn=fn)
+    parts = [cd.sharded_sample_y0(None, x, y0, y0, N_Z, g["T"], g["alphas"], g["omabs"], seed=5, sample_fn=fn,
+                                  gather=False, rank=r, world=3) for r in range(3)]
+    assert [p[1] for p in parts] == [(0, 3), (3, 5), (5, 7)]
+    assert torch.equal(torch.cat([p[0] for p in parts], 0), whole)
+    with pytest.raises(ValueError):
+        cd.sharded_sample_y0(None, x, y0, y0, N_Z, g["T"], g["alphas"], g["omabs"], seed=5, sample_fn=fn, rank=0, world=3)

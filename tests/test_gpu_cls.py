@@ -9,7 +9,7 @@ from card_amd import _lib
 from card_amd.sampler import Sampler, make_coef_table
 from oracle import card_oracle as orc
 from card_amd.synth import cls_state_dict
-from tests.helpers import golden_names, load_golden, norm_rel_err
+from tests.helpers import golden_names, load_golden, norm_rel_err, elem_errs, fmt_errs
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -112,10 +112,29 @@ def test_cls_rng_mode_and_ragged_rows():
         assert torch.isfinite(a).all()
 
 
+@pytest.mark.parametrize("name", golden_names("clsw"))
+def test_cls_wide_widths_match_reference(name):
+    """CIFAR-10 width (F = 4096, C = 10: classification/configs/cifar10.yml:15-19) and a 100-class head against fixtures
+    made by the reference's own ConditionalModel + p_sample_loop carrying card_amd.synth's seeded weights: the fixture
+    holds the seed, the inputs and the reference's trajectory; the weights are regenerated here from the seed."""
+    g = load_golden(name)
+    T, d = g["T"], g["raw"]
+    s = Sampler.from_cls_state_dict(g["sd"], device=DEV)
+    coef = cuda(make_coef_table(g["alphas"], g["omabs"]))
+    xf, y0 = cuda(g["x_feat"]), cuda(g["y0hat"])
+    got = s.run(xf, y0, cuda(g["yTmean"]), coef, T, noise=cuda(g["noise"]), out_mode=_lib.OUT_ALL).cpu()
+    errs = [elem_errs(got[k], g["traj"][k]) for k in range(T + 1)]
+    print(f"{name}: worst per-state {fmt_errs(tuple(max(e[j] for e in errs) for j in range(3)))}")
+    assert max(e[0] for e in errs) <= TOL
+    for t in g["probe_t"]:
+        eps = s.eps_theta(xf, cuda(g["traj"][T - t]), y0, t).cpu()
+        assert norm_rel_err(eps, d[f"eps.t{t}"]) <= TOL, t
+
+
 @pytest.mark.parametrize("F,C", [(4096, 10), (256, 100)])
 def test_cls_wide_widths_against_oracle(F, C):
-    """CIFAR-10 width (F = 4096, C = 10) and a 100-class head: HIP vs the CPU oracle, seeded random weights.
-    (Parity here is pinned by the oracle only: no reference-generated fixture can hold 2 x 64 MB of weights.)"""
+    """CIFAR-10 width (F = 4096, C = 10) and a 100-class head: HIP vs the CPU oracle, seeded random weights, more rows
+    than the reference fixtures above hold (72: a ragged GEMM row tile)."""
     T, N = 6, 72
     sd = cls_state_dict(F, C, T, 3)
     w = orc.ClsWeights.from_state_dict(sd)
@@ -248,3 +267,39 @@ def test_cls_without_guidance_and_class_count_edges(F, C):
         assert worst <= TOL, (guidance, worst)
         eps = s.eps_theta(cuda(xf), cuda(want[2]), cuda(y0), 3).cpu()
         assert norm_rel_err(eps, orc.eps_theta(w, xf, want[2], y0, 3)) <= TOL
+
+
+def test_hoisted_features_follow_the_x_object_not_its_address():
+    """x_features caches norm(encoder_x(x)) per x OBJECT: a per-batch `x = xb.to(dev)` that is freed and whose address the
+    allocator hands to the next batch must get its own features."""
+    g = load_golden("cls_mnist_T50")
+    sd = dict(g["sd"])
+    m = RefShapedCls(sd).to(DEV).eval()
+    m.encoder_x = torch.nn.Linear(128, 128).to(DEV)            # a real (step-invariant) encoder instead of the identity
+    T = g["T"]
+    al, om = cuda(g["alphas"]), cuda(g["omabs"])
+    outs, ptrs = [], []
+    for k in range(3):
+        xb = g["x_feat"] * (1.0 + k)                           # three "batches" of the same shape
+        x = xb.to(DEV)
+        ptrs.append(x.data_ptr())
+        got = card_amd.p_sample_loop(m, x, cuda(g["y0hat"]), cuda(g["yTmean"]), T, al, om, True, noise=cuda(g["noise"]))
+        with torch.no_grad():
+            xf = m.encoder_x(x)
+        s = card_amd.sampler_for(m)
+        want = s.run(xf, cuda(g["y0hat"]), cuda(g["yTmean"]), cuda(make_coef_table(g["alphas"], g["omabs"])), T,
+                     noise=cuda(g["noise"]))
+        assert torch.equal(got, want), k
+        outs.append(got)
+        del x, xf
+    assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2])
+    print("x addresses:", ptrs)
+
+
+def test_bn_model_in_train_mode_is_refused():
+    g = load_golden("cls_mnist_T50")
+    m = RefShapedCls(g["sd"]).to(DEV).eval()
+    args = (cuda(g["x_feat"]), cuda(g["y0hat"]), cuda(g["yTmean"]), g["T"], cuda(g["alphas"]), cuda(g["omabs"]))
+    card_amd.p_sample_loop(m, *args, True, seed=1)              # cached while in eval mode ...
+    with pytest.raises(_lib.CardError, match="eval mode"):      # ... and still refused once switched to train mode
+        card_amd.p_sample_loop(m.train(), *args, True, seed=1)

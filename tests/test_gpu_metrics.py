@@ -1,5 +1,9 @@
-"""On-device regression metrics against a numpy restatement of the reference's helpers
-(regression/card_regression.py:763-825, :866-893)."""
+"""On-device regression metrics against (i) fixtures produced by the reference's own helper closures
+(regression/card_regression.py:763-825, :866-893, extracted and run by oracle/gen_golden.py: tests/golden/metrics_*.npz)
+and (ii) a numpy restatement of those helpers for shapes the fixtures do not hold."""
+import glob
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -7,8 +11,54 @@ from scipy.special import logsumexp
 
 from card_amd import metrics
 
+from card_amd._lib import CardError
+from tests.helpers import GOLDEN, load_raw
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+METRIC_FIXTURES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "metrics_*.npz")))
+
+
+@pytest.mark.parametrize("name", METRIC_FIXTURES)
+def test_row_metrics_match_reference_outputs(name):
+    """card_regression_row_metrics against what compute_prediction_SE / compute_batch_NLL / compute_true_coverage_by_gen_QI /
+    compute_PICP of the reference returned for the same samples: global and per-row precision, with and without the y
+    scaler, trimmed mean (0, 100) / (10, 90) and the median branch (50, 50), n_z = 2 ... 1000.  Integer-valued outputs
+    (decile membership -> coverage ratios, PICP flags) must agree exactly, SE / NLL to fp32 rounding of the reference's
+    own float32 arithmetic (the kernel accumulates in double)."""
+    d = load_raw(name)
+    rows, n_bins = int(d["rows"]), int(d["n_bins"])
+    tau = float(d["tau"])
+    m = metrics.regression_row_metrics(torch.from_numpy(d["gen"]).to(DEV), torch.from_numpy(d["y"]).to(DEV), n_bins=n_bins,
+                                       picp_range=tuple(float(v) for v in d["picp"]),
+                                       trimmed_mean_range=tuple(float(v) for v in d["trim"]), y_scale=float(d["y_scale"]),
+                                       y_shift=float(d["y_shift"]), tau=tau if tau > 0 else None)
+    np.testing.assert_allclose(m["se"][0].cpu().numpy(), d["se"], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(m["nll"][0].cpu().numpy(), d["nll"], rtol=2e-4, atol=2e-4)
+    counts = np.bincount(m["qice_bin"][0].cpu().numpy(), minlength=n_bins + 2).astype(np.int64)
+    counts[1] += counts[0]; counts[-2] += counts[-1]                       # card_regression.py:803-804
+    assert np.array_equal(counts[1:-1] / rows, d["ratio_by_bin"])
+    assert abs(np.absolute(np.ones(n_bins) / n_bins - counts[1:-1] / rows).mean() - float(d["qice"])) < 1e-15
+    assert m["picp_in"][0].double().mean().item() == float(d["picp_coverage"])
+    # the same through the summed form used for the all-reduce
+    sums = metrics.regression_metric_sums(torch.from_numpy(d["gen"]).to(DEV), torch.from_numpy(d["y"]).to(DEV), n_bins=n_bins,
+                                          picp_range=tuple(float(v) for v in d["picp"]),
+                                          trimmed_mean_range=tuple(float(v) for v in d["trim"]), y_scale=float(d["y_scale"]),
+                                          y_shift=float(d["y_shift"]), tau=tau if tau > 0 else None)
+    fin = metrics.finalize(sums, n_bins)
+    assert abs(float(fin["rmse"][0]) - np.sqrt(d["se"].mean())) <= 2e-4 * np.sqrt(d["se"].mean())
+    assert abs(float(fin["qice"][0]) - float(d["qice"])) < 1e-12 and float(fin["picp"][0]) == float(d["picp_coverage"])
+
+
+def test_empty_trim_window_is_rejected():
+    gen = torch.randn(4, 10, device=DEV)
+    y = torch.randn(4, device=DEV)
+    for trim in ((60.0, 40.0), (50.0, 50.4), (95.0, 99.0)):             # int(lo * n) >= int(hi * n) at n_z = 10
+        with pytest.raises(CardError):
+            metrics.regression_row_metrics(gen, y, trimmed_mean_range=trim)
+    ok = metrics.regression_row_metrics(gen, y, trimmed_mean_range=(50.0, 50.0))       # median
+    want = (np.median(gen.cpu().numpy(), axis=1) - y.cpu().numpy()) ** 2
+    np.testing.assert_allclose(ok["se"][0].cpu().numpy(), want, rtol=1e-5, atol=1e-7)
 
 
 def reference_metrics(gen, y, n_bins, picp, trim, scale, shift, tau):

@@ -13,7 +13,7 @@ import card_amd
 from card_amd import _lib
 from card_amd.sampler import Sampler, make_coef_table
 from oracle import card_oracle as orc
-from tests.helpers import golden_names, load_golden, norm_rel_err
+from tests.helpers import golden_names, load_golden, norm_rel_err, elem_errs, fmt_errs
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -73,8 +73,9 @@ def test_free_running_loop_matches_reference(name):
     assert isinstance(seq, list) and len(seq) == T + 1 and seq[0].shape == g["y0hat"].shape
     traj = torch.stack(seq, 0).cpu()
     assert torch.equal(traj[0], g["noise"][0] + g["yTmean"])
-    worst = max(norm_rel_err(traj[k], g["traj"][i]) for i, k in enumerate(g["traj_idx"]))
-    print(f"{name}: worst per-state norm-rel err {worst:.3e}")
+    errs = [elem_errs(traj[k], g["traj"][i]) for i, k in enumerate(g["traj_idx"])]
+    worst = max(e[0] for e in errs)
+    print(f"{name}: worst per-state {fmt_errs(tuple(max(e[j] for e in errs) for j in range(3)))}")
     assert worst <= TOL
     # only_last_sample (classification/diffusion_utils.py:136-139) and a state selection
     y0 = card_amd.p_sample_loop(m, cuda(g["x"]), cuda(g["y0hat"]), cuda(g["yTmean"]), T, cuda(g["alphas"]),
@@ -225,10 +226,72 @@ def test_empty_batch_and_argument_errors():
         s.run(cuda(g["x"][:, :5]), cuda(g["y0hat"]), cuda(g["yTmean"]), coef, g["T"])
     with pytest.raises(_lib.CardError):   # T beyond the gamma tables
         s.run(cuda(g["x"]), cuda(g["y0hat"]), cuda(g["yTmean"]), coef, g["T"] + 5)
-    m = model_of(g).train()
-    with pytest.raises(_lib.CardError):
-        card_amd.p_sample_loop(m, cuda(g["x"]), cuda(g["y0hat"]), cuda(g["yTmean"]), g["T"], cuda(g["alphas"]),
-                               cuda(g["omabs"]))
+    with pytest.raises(_lib.CardError, match="twice"):
+        s.run(cuda(g["x"]), cuda(g["y0hat"]), cuda(g["yTmean"]), coef, g["T"], out_mode=_lib.OUT_SELECT, states=[3, 3])
+    with pytest.raises(_lib.CardError, match="not produced"):       # a single step (state 11 -> 12) cannot fill slot of state 5
+        s.run(cuda(g["x"]), cuda(g["y0hat"]), cuda(g["yTmean"]), coef, g["T"], t_hi=g["T"] - 12, t_lo=g["T"] - 12,
+              y_init=cuda(g["y0hat"]), out_mode=_lib.OUT_SELECT, states=[5, 12])
+
+
+def test_guided_model_samples_in_train_mode_like_the_reference():
+    """ConditionalGuidedModel has no train/eval-dependent layer and the reference samples from it right after model.train()
+    (validation inside Diffusion.train: regression/card_regression.py:365 -> :457, :533): same result as in eval mode."""
+    g = load_golden("reg_boston_T50")
+    m = model_of(g)
+    args = (cuda(g["x"]), cuda(g["y0hat"]), cuda(g["yTmean"]), g["T"], cuda(g["alphas"]), cuda(g["omabs"]))
+    a = card_amd.p_sample_loop(m, *args, True, noise=cuda(g["noise"]))
+    b = card_amd.p_sample_loop(m.train(), *args, True, noise=cuda(g["noise"]))
+    assert torch.equal(a, b) and norm_rel_err(b.cpu(), g["traj"][-1]) <= TOL
+
+
+def test_data_copy_weight_update_is_noticed():
+    """The reference's EMA swap is `param.data.copy_(shadow)` (regression/ema.py:21), which leaves Parameter._version
+    untouched: the content hash taken at every loop entry must catch it."""
+    g, g2 = load_golden("reg_boston_T50"), load_golden("reg_boston_rand_T50")
+    m = model_of(g)
+    args = (cuda(g["x"]), cuda(g["y0hat"]), cuda(g["yTmean"]), g["T"], cuda(g["alphas"]), cuda(g["omabs"]))
+    a = card_amd.p_sample_loop(m, *args, True, noise=cuda(g["noise"]))
+    s_before = card_amd.sampler_for(m)
+    versions = [p._version for p in m.parameters()]
+    for name, p in m.named_parameters():                      # ema.ema(): param.data.copy_(shadow[name].data)
+        p.data.copy_(g2["sd"][name].to(DEV))
+    assert [p._version for p in m.parameters()] == versions   # the blind spot of the identity key
+    b = card_amd.p_sample_loop(m, *args, True, noise=cuda(g["noise"]))
+    assert card_amd.sampler_for(m) is not s_before
+    want = orc.p_sample_loop(g2["weights"], g["x"], g["y0hat"], g["yTmean"], g["T"], g["alphas"], g["omabs"], g["noise"],
+                             only_last_sample=True)
+    assert not torch.equal(a, b) and norm_rel_err(b.cpu(), want) <= TOL
+    card_amd.invalidate(m)
+    assert torch.equal(card_amd.p_sample_loop(m, *args, True, noise=cuda(g["noise"])), b)
+
+
+def test_schedule_temporaries_of_equal_length_do_not_share_a_table():
+    """Two schedules with the same T passed as temporaries (freed after each call, so the allocator hands the same
+    address to the next one): each call must use its own coefficients."""
+    g = load_golden("reg_boston_T50")
+    m, T = model_of(g), g["T"]
+    for end in (0.4, 0.05, 0.4, 0.2):
+        alphas, _, omabs = orc.make_schedule("linear", T, 1e-4, end)
+        got = card_amd.p_sample_loop(m, cuda(g["x"]), cuda(g["y0hat"]), cuda(g["yTmean"]), T, cuda(alphas), cuda(omabs),
+                                     True, noise=cuda(g["noise"]))
+        want = orc.p_sample_loop(g["weights"], g["x"], g["y0hat"], g["yTmean"], T, alphas, omabs, g["noise"],
+                                 only_last_sample=True)
+        assert norm_rel_err(got.cpu(), want) <= TOL, end
+
+
+def test_q_sample_shared_timestep_and_range_check():
+    """card_regression.py:512-514 passes a 1-element t for the whole batch (the reference's extract() broadcasts it)."""
+    g = load_golden("reg_boston_T50")
+    T, N = g["T"], g["x"].shape[0]
+    y, z = cuda(g["traj"][-1]), cuda(g["noise"][3])
+    sab, som = cuda(g["alphas_bar_sqrt"]), cuda(g["omabs"])
+    one = card_amd.q_sample(y, cuda(g["y0hat"]), sab, som, torch.tensor([T - 1]).to(DEV), noise=z)
+    per_row = card_amd.q_sample(y, cuda(g["y0hat"]), sab, som, torch.full((N,), T - 1).to(DEV), noise=z)
+    assert torch.equal(one, per_row)
+    assert torch.equal(one.cpu(), orc.q_sample(g["traj"][-1], g["y0hat"], g["alphas_bar_sqrt"], g["omabs"],
+                                               torch.full((N,), T - 1), g["noise"][3]))
+    with pytest.raises(_lib.CardError, match="outside"):
+        card_amd.q_sample(y, cuda(g["y0hat"]), sab, som, torch.full((N,), T).to(DEV), noise=z)
 
 
 def test_weight_update_invalidates_cached_sampler():
