@@ -13,8 +13,9 @@ COEF_COLS = 8
 EXPORTS = (
     "card_version", "card_last_error", "card_make_coef_table", "card_sampler_create", "card_sampler_destroy",
     "card_sampler_run", "card_sampler_workspace_bytes", "card_eps_theta", "card_q_sample", "card_philox_normal",
-    "card_regression_row_metrics", "card_content_hash",
+    "card_regression_row_metrics", "card_sampler_run_static", "card_content_hash",
 )
+STATIC_SCRATCH_BYTES = 32 << 20
 
 _fp = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -70,6 +71,7 @@ def lib():
     L.card_sampler_destroy.argtypes = [C.c_void_p]
     L.card_sampler_destroy.restype = None
     L.card_sampler_run.argtypes = [C.c_void_p, C.POINTER(RunArgs), C.c_void_p]
+    L.card_sampler_run_static.argtypes = [C.c_void_p, C.POINTER(RunArgs), C.c_void_p]
     L.card_content_hash.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32, C.c_void_p, C.c_void_p]
     L.card_sampler_workspace_bytes.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_uint64)]
     L.card_eps_theta.argtypes = [C.c_void_p, _fp, _fp, _fp, C.c_int64, C.c_int32, _fp, _fp, C.c_uint64, C.c_void_p]

@@ -2,6 +2,7 @@
 // back ends (card_guided.hip: persistent MLP kernel; card_wide.hip: streaming-GEMM classification head),
 // plus the small stand-alone entry points (coefficient table, q_sample, RNG fill).
 #include <new>
+#include <pthread.h>
 
 #include "card_internal.h"
 
@@ -73,7 +74,38 @@ __global__ __launch_bounds__(256) void content_hash_kernel(const HashArgs a, uns
     if ((threadIdx.x & 63) == 0 && h != 0) atomicAdd(out, h);
 }
 
+// ------------------------------------------------------------------------------------------------
+// card_sampler_run_static: the library's own scratch, one copy per GPU, for callers that cannot allocate.
+// `scratch` is the host-side NAME of a device array; its device address is asked for once per device
+// (hipGetSymbolAddress with that device current) and only that pointer is ever handed to kernels.
+// ------------------------------------------------------------------------------------------------
+static __device__ __align__(256) unsigned char scratch[CARD_STATIC_SCRATCH_BYTES];
+constexpr int kMaxDevices = 64;
+void* g_scratch_ptr[kMaxDevices];
+bool g_scratch_known[kMaxDevices];
+pthread_mutex_t g_scratch_mu = PTHREAD_MUTEX_INITIALIZER;
+
 }  // namespace
+
+// The device address of `scratch` on the CURRENT device (looked up on the first call per device, then cached).
+static int static_scratch(int device, void** out) {
+    if (device < 0 || device >= kMaxDevices) return card_fail(CARD_E_UNSUPPORTED, "card_sampler_run_static: device index %d >= %d", device, kMaxDevices);
+    pthread_mutex_lock(&g_scratch_mu);
+    if (!g_scratch_known[device]) {
+        void* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) {
+            pthread_mutex_unlock(&g_scratch_mu);
+            return card_fail(CARD_E_HIP, "card_sampler_run_static: hipGetSymbolAddress(scratch) on device %d: %s", device,
+                             e != hipSuccess ? hipGetErrorString(e) : "null address");
+        }
+        g_scratch_ptr[device] = ptr;
+        g_scratch_known[device] = true;
+    }
+    *out = g_scratch_ptr[device];
+    pthread_mutex_unlock(&g_scratch_mu);
+    return CARD_OK;
+}
 
 int card_fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -168,7 +200,9 @@ extern "C" CARD_API int card_sampler_workspace_bytes(const card_sampler* s, int6
     return CARD_OK;
 }
 
-extern "C" CARD_API int card_sampler_run(const card_sampler* s, const card_run_args* a, void* stream) {
+// shared body of card_sampler_run / card_sampler_run_static: `lib_scratch` != NULL replaces every scratch buffer a
+// back end would otherwise use (the sampler's own per-wave slots, the caller's workspace)
+static int sampler_run(const card_sampler* s, const card_run_args* a, void* stream, void* lib_scratch, unsigned long long lib_scratch_bytes) {
     if (!s || !a) return fail(CARD_E_INVALID, "card_sampler_run: null argument");
     if (a->struct_bytes != (int32_t)sizeof(card_run_args))
         return fail(CARD_E_INVALID, "card_sampler_run: struct_bytes %d != %zu", a->struct_bytes, sizeof(card_run_args));
@@ -196,9 +230,27 @@ extern "C" CARD_API int card_sampler_run(const card_sampler* s, const card_run_a
     r.N = a->N; r.seed = a->seed; r.elem_offset = a->elem_offset;
     r.T = a->T; r.t_hi = a->t_hi; r.t_lo = a->t_lo; r.out_mode = a->out_mode; r.eps_only = 0;
     r.n_z = a->n_z > 1 ? a->n_z : 1;
+    if (lib_scratch) {
+        r.workspace = lib_scratch; r.workspace_bytes = lib_scratch_bytes; r.lib_scratch = 1;
+    }
     return s->backend == 0 ? guided_run(s, r, (hipStream_t)stream)
          : s->backend == 2 ? stream_run(s, r, (hipStream_t)stream)
          : s->backend == 3 ? clscoop_run(s, r, (hipStream_t)stream) : wide_run(s, r, (hipStream_t)stream);
+}
+
+extern "C" CARD_API int card_sampler_run(const card_sampler* s, const card_run_args* a, void* stream) {
+    return sampler_run(s, a, stream, nullptr, 0);
+}
+
+extern "C" CARD_API int card_sampler_run_static(const card_sampler* s, const card_run_args* a, void* stream) {
+    if (!s || !a) return fail(CARD_E_INVALID, "card_sampler_run_static: null argument");
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != s->device)
+        return fail(CARD_E_INVALID, "card_sampler_run_static: the sampler lives on device %d but device %d is current", s->device, dev);
+    void* ptr = nullptr;
+    if (int rc = static_scratch(dev, &ptr)) return rc;
+    return sampler_run(s, a, stream, ptr, CARD_STATIC_SCRATCH_BYTES);
 }
 
 extern "C" CARD_API int card_content_hash(const void* const* arrays, const int64_t* n_words, int32_t n_arrays, uint64_t* out,

@@ -726,6 +726,14 @@ int guided_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     p.x_dim = s->x_dim; p.cat_x = s->cat_x; p.cat_y_pred = s->cat_y_pred;
     p.out_mode = r.out_mode; p.eps_only = r.eps_only; p.n_z = r.n_z;
     p.w1s = s->w1s; p.ws = s->ws; p.nqs = s->nqs;
+    if (r.lib_scratch) {
+        // card_sampler_run_static: the per-wave slots of the scratch-slot kernel come from the library's static array
+        const unsigned long long need = (unsigned long long)s->num_cu * kWaves * kSlotFloats * sizeof(float);
+        if (s->hoist && need > r.workspace_bytes)
+            return card_fail(CARD_E_UNSUPPORTED, "card_sampler_run_static: %d CUs need %llu bytes of wave slots, the static scratch has %llu",
+                             s->num_cu, need, r.workspace_bytes);
+        p.ws = static_cast<float*>(r.workspace);
+    }
     // Split very large N into launches of whole waves-worth of tiles so that one launch stays well under
     // a second and every wave gets the same number of tiles (no intra-launch tail except in the last one).
     // Small batches (the reference's per-minibatch calls).  Measured per 1000 timesteps (tools/bench_small.py): the

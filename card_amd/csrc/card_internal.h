@@ -19,6 +19,8 @@ struct CardRun {
     unsigned long long seed, elem_offset;
     int T, t_hi, t_lo, out_mode, eps_only;
     int n_z;                // >= 1: chains per input row
+    int lib_scratch;        // card_sampler_run_static: `workspace` is the library's per-GPU static array, to be used
+                            // for every scratch buffer of the back end (also in place of the sampler's own slots)
 };
 
 struct card_sampler {

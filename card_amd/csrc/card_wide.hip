@@ -468,6 +468,10 @@ int wide_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     if (!fits) {
         const long long L = (long long)nz / gcd_ll(nz, BM) * BM;        // lcm(n_z, 128)
         chunk = cap >= L ? cap / L * L : cap / nz * nz;
+        if (chunk < 1 && r.lib_scratch)
+            return card_fail(CARD_E_UNSUPPORTED, "card_sampler_run_static: the static scratch of %llu bytes holds %lld chains of this model, fewer "
+                             "than one input row's n_z=%d: beyond the no-allocation entry point's limit (use card_sampler_run with a workspace)",
+                             r.workspace_bytes, cap, nz);
         if (chunk < 1)
             return card_fail(CARD_E_INVALID, "card_sampler_run: workspace of %llu bytes holds %lld chains, fewer than one input row's n_z=%d "
                              "(card_sampler_workspace_bytes reports a sufficient size)", r.workspace_bytes, cap, nz);

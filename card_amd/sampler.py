@@ -174,10 +174,12 @@ class Sampler:
         return t
 
     def run(self, x, y_0_hat, y_T_mean, coef, T, *, t_hi=None, t_lo=0, y_init=None, noise=None, seed=0,
-            elem_offset=0, out_mode=_lib.OUT_LAST, states=None, n_z=1):
+            elem_offset=0, out_mode=_lib.OUT_LAST, states=None, n_z=1, static_scratch=False):
         """card_sampler_run.  Returns (N, y_dim) for OUT_LAST, (n_states, N, y_dim) otherwise.
         n_z > 1: x / y_0_hat / y_T_mean are per test ROW and every row is expanded to n_z chains inside the
-        kernel (N = rows * n_z, chain order (row, z) like regression/card_regression.py:1027-1035)."""
+        kernel (N = rows * n_z, chain order (row, z) like regression/card_regression.py:1027-1035).
+        static_scratch=True goes through card_sampler_run_static: the kernels' scratch comes from the library's per-GPU
+        static array, no workspace is passed (the output tensor is still torch's)."""
         T = int(T)
         t_hi = T - 1 if t_hi is None else int(t_hi)
         t_lo = int(t_lo)
@@ -234,8 +236,11 @@ class Sampler:
         a.seed, a.elem_offset = int(seed) & (2 ** 64 - 1), int(elem_offset)
         a.out, a.out_mode, a.state_slot, a.n_z = _ptr(out), out_mode, _ptr(slot), n_z
         L = _lib.lib()
-        fn, what = L.card_sampler_run, "card_sampler_run"
-        ws, a.workspace, a.workspace_bytes = self._workspace(N)
+        if static_scratch:
+            fn, what = L.card_sampler_run_static, "card_sampler_run_static"
+        else:
+            fn, what = L.card_sampler_run, "card_sampler_run"
+            ws, a.workspace, a.workspace_bytes = self._workspace(N)
         if torch.cuda.current_device() == self.device.index:
             _lib.check(fn(self._h, C.byref(a), _stream(self.device)), what)
         else:

@@ -155,6 +155,18 @@ typedef struct card_run_args {
  * p_sample_t_1to0 (:94-104) with t_hi = t_lo = 0. */
 CARD_API int card_sampler_run(const card_sampler* s, const card_run_args* args, void* stream);
 
+/* card_sampler_run for callers that cannot allocate device memory or pass a workspace: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE.  Same arguments and results as
+ * card_sampler_run (args->workspace / workspace_bytes are ignored); every scratch buffer -- the per-wave layer-1 slots of
+ * the persistent scratch-slot kernel, the activations of the GEMM back end -- lives in ONE array of
+ * CARD_STATIC_SCRATCH_BYTES that the library holds on each GPU it runs on until the process ends.  The call allocates
+ * nothing (no hipMalloc / hipFree, no allocating library routine).  Limits: on the GEMM back end the batch is walked in
+ * chunks of as many chains as the array holds (12 483 at hidden 256, 1 004 at hidden 4096); if not even one input row's
+ * n_z chains fit, the call fails with CARD_E_UNSUPPORTED.  All calls on one GPU share that GPU's array: calls that
+ * overlap in time on one GPU (different streams or threads) race -- order them.  The sampler's device must be current. */
+#define CARD_STATIC_SCRATCH_BYTES (32u << 20)
+CARD_API int card_sampler_run_static(const card_sampler* s, const card_run_args* args, void* stream);
+
 /* 64-bit position-weighted checksum of n_arrays device arrays of 32-bit words (n_words[k] words each), written to the
  * device word *out on `stream`.  No reference counterpart: the Python binding uses it to notice weights that were
  * modified in place behind PyTorch's version counters (the reference's EMA copy, regression/ema.py:21, is
