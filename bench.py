@@ -138,15 +138,17 @@ def main():
     cls_coop = kind == "cls" and H == 128 and y_dim <= 32  # card_clscoop.hip
     x, y0 = x_rows.to(dev), y0_rows.to(dev)
     elem_offset = rank * N * y_dim
-    from card_amd.distributed import regression_metric_sums, all_reduce_sums
+    from card_amd.distributed import all_reduce_sums
+    from card_amd.metrics import regression_metric_sums
 
     def one_step(i):
         y = sampler.run(x, y0, y0, coef, T, seed=1234 + i, elem_offset=elem_offset, out_mode=_lib.OUT_LAST, n_z=a.nz)
         if use_dist:
             # evaluation sums of this rank's rows, then ONE small RCCL all-reduce per loop -- the only collective
             if kind == "guided":
-                # n, squared error, PICP count, QICE bin counts (card_regression.py:776-821): 15 numbers
-                sums = regression_metric_sums(y.reshape(a.rows, a.nz, 1), y_true)
+                # n, sum SE, PICP count, sum NLL, QICE bin counts (card_regression.py:776-821, :866-893): 16 numbers from
+                # the HIP metrics kernel (one workgroup sorts a row's n_z samples in LDS)
+                sums = regression_metric_sums(y.reshape(a.rows, a.nz, 1), y_true, tau=1.0)
             else:
                 # predicted-label histogram of the per-image mean sample (card_classification.py:1010-1020)
                 sums = torch.bincount(y.reshape(a.rows, a.nz, y_dim).mean(1).argmax(1), minlength=y_dim).double()
@@ -202,6 +204,19 @@ def main():
             kernel = "wide_gemm_kernel<EPI_SOFTPLUS> (+ layer-1 / head GEMM and update launches, all inside the timed region)"
         avg_launch_ms = ev_ms / launches
         achieved = (float(N) * T * a.steps * flops_per_unit) / (ev_ms * 1e-3) / 1e12
+        # flops the kernels actually issue per sample-step (`achieved` prices the ALGORITHMIC count of SURVEY.md 8d, which
+        # the hoisted layer 1 undercuts -- on the Year shape by 26 % -- and K / class padding overshoots)
+        if persistent and H == 128:
+            nqs = (d_in - 1 + 7) // 8
+            executed = 2 * H * (2 * H) + 2 * H * 2 + 2 * H + 2 * H * 8 * nqs / T     # layers 2-3, K=2 update of layer 1, lin4 (VALU), hoist / T
+        elif persistent:
+            ks1 = next(k for k in (2, 4, 8, 16, 24) if (d_in + 3) // 4 <= k)
+            executed = 2 * H * (4 * ks1 + 2 * H) + 2 * H                              # card_stream.hip: layer 1 on MFMA every step, K padded
+        elif cls_coop:
+            executed = 2 * H * (8 * ((y_dim + 7) // 8) + 2 * H + 32)                  # card_clscoop.hip: y_t columns in 8s, lin4 as a 32-class MFMA tile
+        else:
+            executed = 2 * H * (32 * ((d_in + 31) // 32) + 2 * H + 128 * ((y_dim + 127) // 128))   # card_wide.hip: K and head padded
+        achieved_exec = achieved * executed / flops_per_unit
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if persistent and os.path.exists(tpath):
@@ -222,6 +237,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
                          "kernel": kernel, "flops_per_sample_step": flops_per_unit,
+                         "flops_executed_per_sample_step": executed, "achieved_executed": achieved_exec,
+                         "frac_executed": achieved_exec / PEAK_FP32_MATRIX_TFLOPS,
                          "launches": launches, "avg_launch_ms": avg_launch_ms},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -1,0 +1,77 @@
+"""The multi-GPU host path on the hardware a test box has (one MI355X): the default (HIP) sampler behind
+`sharded_sample_y0`, shards emulated with the rank / world overrides, and the RCCL branches (all_gather of the samples,
+all_reduce of the metric sums) under a one-rank nccl process group.  The world-size-2 logic is covered on CPU with gloo
+(tests/test_distributed_gloo.py); a measured multi-GPU run is the driver's (bench.py --gpus N)."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+
+import card_amd
+from card_amd import distributed as cd
+from card_amd import metrics
+from tests.helpers import load_golden
+from tests.test_gpu_parity import model_of
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def cuda(t):
+    return t.to(DEV)
+
+
+def _problem(rows=23, n_z=40):
+    g = load_golden("reg_boston_T50")
+    gen = torch.Generator().manual_seed(3)
+    idx = torch.randint(0, g["x"].shape[0], (rows,), generator=gen)
+    x = g["x"][idx] + 0.05 * torch.randn(rows, g["x"].shape[1], generator=gen)
+    y0 = g["y0hat"][idx] + 0.05 * torch.randn(rows, 1, generator=gen)
+    return g, model_of(g), cuda(x), cuda(y0), n_z
+
+
+def test_emulated_shards_on_the_gpu_equal_one_call():
+    """Two (and three) shards sampled one after the other with the default HIP sampler == one call over all rows, bit for
+    bit: row blocks + elem_offset make the Philox streams independent of the sharding."""
+    g, m, x, y0, n_z = _problem()
+    al, om = cuda(g["alphas"]), cuda(g["omabs"])
+    whole = cd.sharded_sample_y0(m, x, y0, y0, n_z, g["T"], al, om, seed=77)        # no process group: one shard
+    assert whole.shape == (x.shape[0], n_z, 1)
+    direct = card_amd.p_sample_loop(m, x, y0, y0, g["T"], al, om, True, seed=77, n_z=n_z)
+    assert torch.equal(whole.reshape(-1, 1), direct)
+    for world in (2, 3):
+        parts = [cd.sharded_sample_y0(m, x, y0, y0, n_z, g["T"], al, om, seed=77, gather=False, rank=r, world=world)
+                 for r in range(world)]
+        assert [p[1] for p in parts] == [cd.row_shard(x.shape[0], r, world) for r in range(world)]
+        assert torch.equal(torch.cat([p[0] for p in parts], 0), whole), world
+
+
+@pytest.fixture()
+def one_rank_nccl():
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    port = 29600 + os.getpid() % 1000
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device(DEV))
+    try:
+        yield
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_branches_under_a_one_rank_group(one_rank_nccl):
+    """gather=True goes through dist.all_gather (padded shards, trimmed), the metric sums through dist.all_reduce, both on
+    RCCL with device tensors; with one rank they must return what the local computation gives."""
+    g, m, x, y0, n_z = _problem(rows=11, n_z=64)
+    al, om = cuda(g["alphas"]), cuda(g["omabs"])
+    local, (lo, hi) = cd.sharded_sample_y0(m, x, y0, y0, n_z, g["T"], al, om, seed=5, gather=False)
+    assert (lo, hi) == (0, 11)
+    full = cd.sharded_sample_y0(m, x, y0, y0, n_z, g["T"], al, om, seed=5, gather=True)
+    assert torch.equal(full, local)
+    y_true = y0 + 0.2
+    fin, sums = cd.sharded_regression_metrics(local, y_true, tau=1.0)
+    want = metrics.regression_metric_sums(local, y_true, tau=1.0)
+    assert torch.equal(sums, want) and sums.shape == (1, 16) and float(sums[0, 0]) == 11
+    one = metrics.finalize(want)
+    for k in ("rmse", "picp", "nll", "qice"):
+        assert float(fin[k][0]) == float(one[k][0])
