@@ -10,12 +10,14 @@ from .diffusion_utils import (  # noqa: F401
     make_beta_schedule,
     p_sample,
     p_sample_loop,
+    p_sample_loop_from_x,
     p_sample_loop_with_eval,
     p_sample_loop_with_y,
     p_sample_t_1to0,
     q_sample,
     y_0_reparam,
 )
+from .guidance import GuidanceNet, guidance_for  # noqa: F401
 from .sampler import Sampler, invalidate, sampler_for  # noqa: F401
 
-__version__ = "0.2.0"
+__version__ = "0.2.1"

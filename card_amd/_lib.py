@@ -14,7 +14,9 @@ EXPORTS = (
     "card_version", "card_last_error", "card_make_coef_table", "card_sampler_create", "card_sampler_destroy",
     "card_sampler_run", "card_sampler_workspace_bytes", "card_eps_theta", "card_q_sample", "card_philox_normal",
     "card_regression_row_metrics", "card_sampler_run_static", "card_content_hash",
+    "card_fphi_create", "card_fphi_destroy", "card_fphi_forward",
 )
+FPHI_MAX_LAYERS, FPHI_MAX_WIDTH = 8, 1024
 STATIC_SCRATCH_BYTES = 32 << 20
 
 _fp = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
@@ -35,6 +37,15 @@ class RunArgs(C.Structure):
         ("N", C.c_int64), ("x", _fp), ("y_0_hat", _fp), ("y_T_mean", _fp), ("y_init", _fp), ("coef", _fp),
         ("noise", _fp), ("seed", C.c_uint64), ("elem_offset", C.c_uint64), ("out", _fp),
         ("out_mode", C.c_int32), ("n_z", C.c_int32), ("state_slot", _fp), ("workspace", _fp), ("workspace_bytes", C.c_uint64),
+        ("fphi", _fp), ("fphi_out", _fp),
+    ]
+
+
+class FphiDesc(C.Structure):
+    _fields_ = [
+        ("struct_bytes", C.c_int32), ("n_layers", C.c_int32), ("dims", C.c_int32 * (FPHI_MAX_LAYERS + 1)),
+        ("negative_slope", C.c_float), ("W", _fp * FPHI_MAX_LAYERS), ("b", _fp * FPHI_MAX_LAYERS),
+        ("bn_scale", _fp * FPHI_MAX_LAYERS), ("bn_shift", _fp * FPHI_MAX_LAYERS),
     ]
 
 
@@ -78,6 +89,10 @@ def lib():
     L.card_q_sample.argtypes = [_fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_uint64,
                                 C.c_uint64, _fp, C.c_void_p]
     L.card_regression_row_metrics.argtypes = [C.POINTER(MetricArgs), C.c_void_p]
+    L.card_fphi_create.argtypes = [C.POINTER(FphiDesc), C.c_void_p, C.POINTER(C.c_void_p)]
+    L.card_fphi_destroy.argtypes = [C.c_void_p]
+    L.card_fphi_destroy.restype = None
+    L.card_fphi_forward.argtypes = [C.c_void_p, _fp, C.c_int64, _fp, C.c_void_p]
     L.card_philox_normal.argtypes = [C.c_uint64, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_void_p]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = a symbol the header declares is not exported

@@ -215,16 +215,30 @@ static int sampler_run(const card_sampler* s, const card_run_args* a, void* stre
         return fail(CARD_E_INVALID, "card_sampler_run: y_init == NULL starts a loop and needs t_hi == T-1");
     if (a->out_mode < CARD_OUT_LAST || a->out_mode > CARD_OUT_SELECT) return fail(CARD_E_INVALID, "card_sampler_run: bad out_mode");
     if (a->N == 0) return CARD_OK;  // empty batch: nothing to read or write
-    if (!a->y_0_hat || !a->y_T_mean || !a->coef || !a->out)
+    if (a->n_z < 0 || (a->n_z > 1 && a->N % a->n_z != 0))
+        return fail(CARD_E_INVALID, "card_sampler_run: N=%lld is not a multiple of n_z=%d", (long long)a->N, a->n_z);
+    const float* y0hat = a->y_0_hat;
+    const float* ytmean = a->y_T_mean;
+    if (a->fphi) {
+        // regression/card_regression.py:1021: y_0_hat = f_phi(x) over the un-tiled rows, first kernel of this call
+        if (s->variant != CARD_VARIANT_GUIDED) return fail(CARD_E_UNSUPPORTED, "card_sampler_run: fphi is for CARD_VARIANT_GUIDED (regression) samplers");
+        if (!a->x || !a->fphi_out) return fail(CARD_E_INVALID, "card_sampler_run: fphi needs x and fphi_out");
+        if (fphi_out_dim(a->fphi) != s->y_dim)
+            return fail(CARD_E_INVALID, "card_sampler_run: f_phi produces %d outputs, the sampler's y_dim is %d", fphi_out_dim(a->fphi), s->y_dim);
+        if (s->cat_x && fphi_in_dim(a->fphi) != s->x_dim)
+            return fail(CARD_E_INVALID, "card_sampler_run: f_phi reads %d features, eps_theta's x has %d", fphi_in_dim(a->fphi), s->x_dim);
+        if (int rc = fphi_forward(a->fphi, a->x, a->N / (a->n_z > 1 ? a->n_z : 1), a->fphi_out, (hipStream_t)stream)) return rc;
+        y0hat = a->fphi_out;
+        if (!ytmean) ytmean = a->fphi_out;
+    }
+    if (!y0hat || !ytmean || !a->coef || !a->out)
         return fail(CARD_E_INVALID, "card_sampler_run: null y_0_hat / y_T_mean / coef / out");
     const bool need_x = s->variant != CARD_VARIANT_GUIDED || (s->cat_x && s->x_dim > 0);
     if (need_x && !a->x) return fail(CARD_E_INVALID, "card_sampler_run: x is NULL but the model reads x");
     if (a->out_mode == CARD_OUT_SELECT && !a->state_slot) return fail(CARD_E_INVALID, "card_sampler_run: CARD_OUT_SELECT needs state_slot");
-    if (a->n_z < 0 || (a->n_z > 1 && a->N % a->n_z != 0))
-        return fail(CARD_E_INVALID, "card_sampler_run: N=%lld is not a multiple of n_z=%d", (long long)a->N, a->n_z);
     CardRun r;
     memset(&r, 0, sizeof(r));
-    r.x = a->x; r.y0hat = a->y_0_hat; r.ytmean = a->y_T_mean; r.y_init = a->y_init; r.coef = a->coef;
+    r.x = a->x; r.y0hat = y0hat; r.ytmean = ytmean; r.y_init = a->y_init; r.coef = a->coef;
     r.noise = a->noise; r.out = a->out; r.state_slot = a->state_slot;
     r.workspace = a->workspace; r.workspace_bytes = a->workspace_bytes;
     r.N = a->N; r.seed = a->seed; r.elem_offset = a->elem_offset;

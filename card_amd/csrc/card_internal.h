@@ -61,6 +61,11 @@ int stream_create(card_sampler* s, const card_model_desc* d, hipStream_t stream)
 void stream_destroy(card_sampler* s);
 int stream_run(const card_sampler* s, const CardRun& r, hipStream_t stream);
 
+// card_fphi.hip: the guidance network evaluated at the head of a sampling call
+int fphi_in_dim(const card_fphi* f);
+int fphi_out_dim(const card_fphi* f);
+int fphi_forward(const card_fphi* f, const float* x, long long rows, float* out, hipStream_t stream);
+
 bool clscoop_supports(const card_model_desc* d);
 int clscoop_create(card_sampler* s, const card_model_desc* d, hipStream_t stream);
 void clscoop_destroy(card_sampler* s);

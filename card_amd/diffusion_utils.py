@@ -20,7 +20,7 @@ from .sampler import (coef_on_device, make_coef_table, sampler_for, x_features, 
 # every public name of regression/diffusion_utils.py and classification/diffusion_utils.py (the runners star-import the
 # module: regression/card_regression.py:16 uses kld at :685), plus this package's extras
 __all__ = ["make_beta_schedule", "extract", "q_sample", "p_sample", "p_sample_t_1to0", "p_sample_loop", "kld",
-           "y_0_reparam", "p_sample_loop_with_eval", "p_sample_loop_with_y"]
+           "y_0_reparam", "p_sample_loop_with_eval", "p_sample_loop_with_y", "p_sample_loop_from_x"]
 
 
 def make_beta_schedule(schedule="linear", num_timesteps=1000, start=1e-5, end=1e-2):
@@ -185,6 +185,33 @@ def p_sample_loop_with_y(model, x, y, y_0_hat, y_T_mean, T, alphas, one_minus_al
         if y.dim() != 2 or y.shape[1] != y_0_hat.shape[1] or int(y.shape[0]) not in (rows, rows * n_z):
             raise CardError(f"p_sample_loop_with_y: y {tuple(y.shape)} does not match y_0_hat {tuple(y_0_hat.shape)}")
     return p_sample_loop(model, x, y_0_hat, y_T_mean, T, alphas, one_minus_alphas_bar_sqrt, **kw)
+
+
+def p_sample_loop_from_x(model, f_phi, x, n_steps, alphas, one_minus_alphas_bar_sqrt, *, n_z=1, noise_prior=False,
+                         only_last_sample=False, noise=None, seed=None, elem_offset=0, states=None):
+    """The body of the reference's test loop in one call, regression/card_regression.py:1021-1044: y_0_hat = f_phi(x)
+    (compute_guiding_prediction, :111-124), y_T_mean = y_0_hat or zeros for `noise_prior` (:1031-1033), every test row
+    repeated n_z times (:1027-1035), then p_sample_loop (:1043).  Here the guidance network is the first kernel of the
+    sampling call and the tiling happens inside the sampling kernels, so x is read once per row and no tiled copy of
+    x / y_0_hat / y_T_mean exists.  `f_phi`: the reference's DeterministicFeedForwardNeuralNetwork (regression/model.py:55)
+    in eval mode, an OLS coefficient tensor (1 + x_dim, y_dim), or a card_amd.guidance.GuidanceNet.
+    Returns (what p_sample_loop returns, y_0_hat (rows, y_dim))."""
+    from .guidance import guidance_for
+    s = sampler_for(model)
+    g = guidance_for(f_phi)
+    T = int(n_steps)
+    coef = coef_on_device(alphas, one_minus_alphas_bar_sqrt, T, s.device)
+    seed = _fresh_seed() if (seed is None and noise is None) else int(seed or 0)
+    rows = int(x.shape[0])
+    mu = torch.zeros(rows, s.y_dim, device=s.device) if noise_prior else None
+    y0hat = torch.empty(rows, s.y_dim, device=s.device, dtype=torch.float32)
+    kw = dict(noise=noise, seed=seed, elem_offset=elem_offset, n_z=n_z, fphi=g, fphi_out=y0hat)
+    if states is not None:
+        return s.run(x, None, mu, coef, T, out_mode=_lib.OUT_SELECT, states=states, **kw), y0hat
+    if only_last_sample:
+        return s.run(x, None, mu, coef, T, out_mode=_lib.OUT_LAST, **kw), y0hat
+    seq = s.run(x, None, mu, coef, T, out_mode=_lib.OUT_ALL, **kw)
+    return list(seq.unbind(0)), y0hat
 
 
 def kld(y1, y2, grid=(-20, 20), num_grid=400):

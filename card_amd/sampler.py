@@ -174,22 +174,38 @@ class Sampler:
         return t
 
     def run(self, x, y_0_hat, y_T_mean, coef, T, *, t_hi=None, t_lo=0, y_init=None, noise=None, seed=0,
-            elem_offset=0, out_mode=_lib.OUT_LAST, states=None, n_z=1, static_scratch=False):
+            elem_offset=0, out_mode=_lib.OUT_LAST, states=None, n_z=1, static_scratch=False, fphi=None, fphi_out=None):
         """card_sampler_run.  Returns (N, y_dim) for OUT_LAST, (n_states, N, y_dim) otherwise.
         n_z > 1: x / y_0_hat / y_T_mean are per test ROW and every row is expanded to n_z chains inside the
         kernel (N = rows * n_z, chain order (row, z) like regression/card_regression.py:1027-1035).
         static_scratch=True goes through card_sampler_run_static: the kernels' scratch comes from the library's per-GPU
-        static array, no workspace is passed (the output tensor is still torch's)."""
+        static array, no workspace is passed (the output tensor is still torch's).
+        fphi = a card_amd.guidance.GuidanceNet: y_0_hat = f_phi(x) is computed inside the call (first kernel) into
+        `fphi_out` ((rows, y_dim), allocated when None; kept as self.last_y_0_hat); y_0_hat is ignored and y_T_mean=None
+        means y_T_mean = y_0_hat (regression/card_regression.py:1021-1035)."""
         T = int(T)
         t_hi = T - 1 if t_hi is None else int(t_hi)
         t_lo = int(t_lo)
-        y0 = self._prep(y_0_hat, self.y_dim, "y_0_hat")
-        mu = self._prep(y_T_mean, self.y_dim, "y_T_mean")
         n_z = max(1, int(n_z))
-        rows = int(y0.shape[0])
+        if fphi is not None:
+            if self.variant != _lib.VARIANT_GUIDED:
+                raise CardError("fphi is for regression (GUIDED) samplers")
+            xx = self._prep(x, fphi.dim_in, "x")
+            rows = int(xx.shape[0])
+            if fphi_out is None:
+                fphi_out = torch.empty(rows, self.y_dim, device=self.device, dtype=torch.float32)
+            elif not (fphi_out.dtype is torch.float32 and fphi_out.device == self.device and fphi_out.is_contiguous()
+                      and tuple(fphi_out.shape) == (rows, self.y_dim)):
+                raise CardError(f"fphi_out must be a contiguous fp32 ({rows}, {self.y_dim}) tensor on {self.device}")
+            y0 = self.last_y_0_hat = fphi_out
+            mu = self._prep(y_T_mean, self.y_dim, "y_T_mean") if y_T_mean is not None else None
+        else:
+            y0 = self._prep(y_0_hat, self.y_dim, "y_0_hat")
+            mu = self._prep(y_T_mean, self.y_dim, "y_T_mean")
+            rows = int(y0.shape[0])
+            need_x = self.variant != _lib.VARIANT_GUIDED or (self.cat_x and self.x_dim > 0)
+            xx = self._prep(x, self.x_dim, "x") if need_x else None
         N = rows * n_z
-        need_x = self.variant != _lib.VARIANT_GUIDED or (self.cat_x and self.x_dim > 0)
-        xx = self._prep(x, self.x_dim, "x") if need_x else None
         yi = self._prep(y_init, self.y_dim, "y") if y_init is not None else None
         for name, t, want in (("x", xx, rows), ("y_T_mean", mu, rows), ("y", yi, N)):
             if t is not None and t.shape[0] != want:
@@ -235,6 +251,8 @@ class Sampler:
         a.coef, a.noise = _ptr(coef), _ptr(nz)
         a.seed, a.elem_offset = int(seed) & (2 ** 64 - 1), int(elem_offset)
         a.out, a.out_mode, a.state_slot, a.n_z = _ptr(out), out_mode, _ptr(slot), n_z
+        if fphi is not None:
+            a.fphi, a.fphi_out = fphi._h, _ptr(fphi_out)
         L = _lib.lib()
         if static_scratch:
             fn, what = L.card_sampler_run_static, "card_sampler_run_static"

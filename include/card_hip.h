@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CARD_HIP_VERSION 200 /* major*10000 + minor*100 + patch */
+#define CARD_HIP_VERSION 210 /* major*10000 + minor*100 + patch */
 #define CARD_API __attribute__((visibility("default")))
 
 typedef enum card_status {
@@ -98,6 +98,30 @@ typedef struct card_model_desc {
 
 typedef struct card_sampler card_sampler;
 
+/* The guidance network f_phi that produces y_0_hat (and y_T_mean) from x, exactly as the reference's state_dict holds it.
+ * Replaces: DeterministicFeedForwardNeuralNetwork.forward (regression/model.py:55-82; eval mode: Dropout is the identity,
+ * BatchNorm1d is folded to a per-feature scale / shift by the caller) behind Diffusion.compute_guiding_prediction
+ * (regression/card_regression.py:111-124, method "NN"); method "OLS" (`cat(1, x).mm(beta)`, :115-117) is the one-layer
+ * case W = beta[1:].T, b = beta[0].  All device pointers; copied at create time. */
+#define CARD_FPHI_MAX_LAYERS 8
+#define CARD_FPHI_MAX_WIDTH 1024
+typedef struct card_fphi_desc {
+    int32_t struct_bytes;                        /* sizeof(card_fphi_desc) */
+    int32_t n_layers;                            /* nn.Linear layers, output layer included: len(hid_layers) + 1 */
+    int32_t dims[CARD_FPHI_MAX_LAYERS + 1];      /* dims[0] = dim_in, dims[l + 1] = out features of layer l, dims[n_layers] = dim_out */
+    float negative_slope;                        /* LeakyReLU slope (regression/model.py:65, :76) */
+    const float* W[CARD_FPHI_MAX_LAYERS];        /* (dims[l + 1], dims[l]) nn.Linear weight */
+    const float* b[CARD_FPHI_MAX_LAYERS];        /* (dims[l + 1]) or NULL */
+    const float* bn_scale[CARD_FPHI_MAX_LAYERS]; /* use_batchnorm (model.py:74-75), hidden layers: weight / sqrt(running_var + eps); else NULL */
+    const float* bn_shift[CARD_FPHI_MAX_LAYERS]; /* bias - running_mean * scale; else NULL */
+} card_fphi_desc;
+
+typedef struct card_fphi card_fphi;
+CARD_API int card_fphi_create(const card_fphi_desc* desc, void* stream, card_fphi** out);
+CARD_API void card_fphi_destroy(card_fphi* f);
+/* out (rows, dim_out) = f_phi(x (rows, dim_in)).  Replaces: compute_guiding_prediction (regression/card_regression.py:111-124). */
+CARD_API int card_fphi_forward(const card_fphi* f, const float* x, int64_t rows, float* out, void* stream);
+
 /* Library version (CARD_HIP_VERSION of the build). */
 CARD_API int card_version(void);
 
@@ -146,6 +170,13 @@ typedef struct card_run_args {
                                walk the batch in chunks of as many chains as fit, at least n_z).  NULL for samplers on
                                the persistent kernels (card_sampler_workspace_bytes reports 0). */
     uint64_t workspace_bytes;
+    const card_fphi* fphi;  /* not NULL (GUIDED only): the call first evaluates y_0_hat = f_phi(x) over the N / max(n_z, 1) un-tiled
+                               rows of x (x is then (rows, dim_in of f_phi) and must not be NULL) into fphi_out and samples with
+                               it -- regression/card_regression.py:1021-1035 (compute_guiding_prediction, then the n_z tiling)
+                               inside the call.  y_0_hat is ignored; y_T_mean == NULL means y_T_mean = y_0_hat (:1031), pass
+                               zeros for config.diffusion.noise_prior (:1032-1033). */
+    float* fphi_out;        /* device (rows, y_dim), required with fphi: receives y_0_hat = f_phi(x) (the caller's metrics need
+                               it too, and so the call allocates nothing) */
 } card_run_args;
 
 /* Run timesteps t_hi ... t_lo of the reverse process for N independent chains (persistent kernels: one launch per

@@ -22,6 +22,7 @@ to the reference for a given injected noise tensor:
   * p_sample_loop          <- regression/diffusion_utils.py:107-119,
                               classification/diffusion_utils.py:119-144
   * q_sample               <- regression/diffusion_utils.py:42-53
+  * f_phi (guidance net)   <- regression/model.py:55-82 (eval mode), OLS guidance regression/card_regression.py:115-117
 
 Parity pin: the reference ships no tests or golden vectors for this path
 (SURVEY.md section 4), so the oracle is pinned by fixtures produced by importing
@@ -275,6 +276,30 @@ def q_sample(y, y_0_hat, alphas_bar_sqrt, one_minus_alphas_bar_sqrt, t, noise):
     sab = torch.gather(alphas_bar_sqrt, 0, t).reshape(*shape)
     somab = torch.gather(one_minus_alphas_bar_sqrt, 0, t).reshape(*shape)
     return sab * y + (1 - sab) * y_0_hat + somab * noise
+
+
+def fphi_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, negative_slope: float = 0.01, bn_eps: float = 1e-5):
+    """DeterministicFeedForwardNeuralNetwork.forward in eval mode (regression/model.py:70-82): per hidden layer
+    Linear -> [BatchNorm1d with running statistics] -> LeakyReLU -> Dropout (identity), then a plain Linear.
+    sd: the module's state_dict ("network.<i>.weight" ...; a 1-D "weight" belongs to a BatchNorm1d)."""
+    idx = sorted({int(k.split(".")[1]) for k in sd if k.startswith("network.")})
+    lin = [i for i in idx if sd[f"network.{i}.weight"].dim() == 2]
+    h = x
+    for n, i in enumerate(lin):
+        h = torch.addmm(sd[f"network.{i}.bias"], h, sd[f"network.{i}.weight"].t())
+        if n == len(lin) - 1:
+            return h
+        j = i + 1
+        if f"network.{j}.running_mean" in sd:
+            h = (h - sd[f"network.{j}.running_mean"]) / torch.sqrt(sd[f"network.{j}.running_var"] + bn_eps) \
+                * sd[f"network.{j}.weight"] + sd[f"network.{j}.bias"]
+        h = torch.nn.functional.leaky_relu(h, negative_slope)
+    return h
+
+
+def ols_forward(beta: torch.Tensor, x: torch.Tensor):
+    """compute_guiding_prediction(method="OLS"), regression/card_regression.py:115-117."""
+    return torch.cat((torch.ones(x.shape[0], 1, dtype=x.dtype), x), dim=1).mm(beta)
 
 
 def make_beta_schedule(schedule="linear", num_timesteps=1000, start=1e-5, end=1e-2):

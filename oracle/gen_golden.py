@@ -351,17 +351,28 @@ def gen_metrics(name, rows, n_z, seed, *, scaler, tau, trim, n_bins=10, picp=(2.
     print(f"{name}: rows={rows} n_z={n_z} rmse={np.sqrt(np.mean(se)):.4f} nll={np.mean(nll):.4f} qice={qice:.4f} picp={cover:.4f}")
 
 
-def gen_fphi(reg_model, name, x_dim, N, seed):
+def gen_fphi(reg_model, name, x_dim, N, seed, hid_layers=(100, 50), use_batchnorm=False, slope=0.01):
     """regression/model.py:55-82 DeterministicFeedForwardNeuralNetwork (the guidance net f_phi of the UCI configs:
-    hidden 100, 50, LeakyReLU 0.01, no batch norm, dropout 0.2 = identity in eval mode: regression/configs/uci_boston.yml:31-39)."""
+    hidden 100, 50, LeakyReLU 0.01, no batch norm, dropout 0.2 = identity in eval mode: regression/configs/uci_boston.yml:31-39).
+    use_batchnorm: a few train-mode forward passes first, so that the running statistics are not the identity."""
     torch.manual_seed(seed)
-    net = reg_model.DeterministicFeedForwardNeuralNetwork(dim_in=x_dim, dim_out=1, hid_layers=[100, 50],
-                                                          use_batchnorm=False, negative_slope=0.01,
-                                                          dropout_rate=0.2).eval()
+    net = reg_model.DeterministicFeedForwardNeuralNetwork(dim_in=x_dim, dim_out=1, hid_layers=list(hid_layers),
+                                                          use_batchnorm=use_batchnorm, negative_slope=slope,
+                                                          dropout_rate=0.2)
+    if use_batchnorm:
+        net.train()
+        with torch.no_grad():
+            for m in net.network.children():
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.weight.uniform_(0.5, 1.5)
+                    m.bias.normal_(0, 0.3)
+            for _ in range(20):
+                net(torch.randn(256, x_dim) * 1.7 + 0.4)
+    net.eval()
     x = torch.randn(N, x_dim)
     with torch.no_grad():
         y = net(x)
-    np.savez(os.path.join(OUT, name + ".npz"), kind="fphi", x=x.numpy(), y=y.numpy(), negative_slope=0.01,
+    np.savez(os.path.join(OUT, name + ".npz"), kind="fphi", x=x.numpy(), y=y.numpy(), negative_slope=slope,
              **sd_arrays(net))
     print(f"{name}: N={N} x_dim={x_dim} keys={list(net.state_dict())}")
 
@@ -415,6 +426,7 @@ def main():
     M("metrics_nz257_median", 97, 257, 6, scaler=False, tau=None, trim=(50, 50))
     job("fphi_boston", gen_fphi, reg_model, "fphi_boston", 13, 64, 41)
     job("fphi_year", gen_fphi, reg_model, "fphi_year", 90, 64, 42)
+    job("fphi_bn_wide", gen_fphi, reg_model, "fphi_bn_wide", 8, 37, 43, hid_layers=(64, 200, 32), use_batchnorm=True, slope=0.2)
 
 
 if __name__ == "__main__":

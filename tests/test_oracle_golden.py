@@ -106,3 +106,13 @@ def test_philox_normal_moments():
     z = orc.philox_noise(1234, 8, 50000, 1).numpy().reshape(-1)
     assert abs(z.mean()) < 0.01 and abs(z.std() - 1.0) < 0.01
     assert abs((z ** 3).mean()) < 0.03 and abs((z ** 4).mean() - 3.0) < 0.08
+
+
+@pytest.mark.parametrize("name", ["fphi_boston", "fphi_year", "fphi_bn_wide"])
+def test_fphi_matches_reference(name):
+    """The oracle's f_phi (regression/model.py:55-82, eval mode) against the reference module's own output."""
+    from tests.helpers import load_raw
+    d = load_raw(name)
+    sd = {k[3:]: torch.from_numpy(v) for k, v in d.items() if k.startswith("sd.")}
+    got = orc.fphi_forward(sd, torch.from_numpy(d["x"]), float(d["negative_slope"]))
+    assert norm_rel_err(got, d["y"]) <= TOL
