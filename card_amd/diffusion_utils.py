@@ -93,19 +93,116 @@ def q_sample(y, y_0_hat, alphas_bar_sqrt, one_minus_alphas_bar_sqrt, t, noise=No
     return out
 
 
+class _StepCtx:
+    """Everything the per-timestep entry points re-derive from their arguments, kept between the T calls of one loop
+    (classification/card_classification.py:645-653, :665-670 call p_sample T - 1 times and p_sample_t_1to0 once with the
+    SAME model / x / y_0_hat / y_T_mean / schedule objects; only y and t change).  Holds those objects, so their ids cannot
+    be recycled while the entry lives, and two pre-filled card_run_args (steps t >= 1, and the t = 0 step with its own
+    one-row table)."""
+    __slots__ = ("model", "x", "y_0_hat", "y_T_mean", "alphas", "omabs", "sampler", "params", "versions", "in_versions",
+                 "xx", "y0", "mu", "coef", "coef0", "args", "args0", "N", "T", "seed", "last_t", "fn", "ws")
+
+
+_step_ctx = None
+
+
+def _step_ctx_for(model, x, y_0_hat, y_T_mean, alphas, omabs, fresh):
+    """The cached context of this (model, inputs, schedule) combination, or a new one.  `fresh` (first step of a loop)
+    re-validates the weights by identity and content (sampler_for); later steps of the loop only compare the parameters'
+    version counters (a few microseconds), which catches optimizer steps / load_state_dict / in-place edits."""
+    global _step_ctx
+    c = _step_ctx
+    if (c is not None and not fresh and c.model is model and c.x is x and c.y_0_hat is y_0_hat and c.y_T_mean is y_T_mean
+            and c.alphas is alphas and c.omabs is omabs
+            and c.in_versions == (x._version if x is not None else 0, y_0_hat._version, y_T_mean._version, omabs._version)):
+        for p, v in zip(c.params, c.versions):
+            if p._version != v:
+                break
+        else:
+            return c
+    s = sampler_for(model, check_content=fresh)
+    c = _StepCtx()
+    c.model, c.x, c.y_0_hat, c.y_T_mean, c.alphas, c.omabs, c.sampler = model, x, y_0_hat, y_T_mean, alphas, omabs, s
+    from .sampler import _tensors
+    c.params = _tensors(model)
+    c.versions = [p._version for p in c.params]
+    c.in_versions = (x._version if x is not None else 0, y_0_hat._version, y_T_mean._version, omabs._version)
+    c.y0 = s._prep(y_0_hat, s.y_dim, "y_0_hat")
+    c.mu = s._prep(y_T_mean, s.y_dim, "y_T_mean")
+    c.N = int(c.y0.shape[0])
+    need_x = s.variant != _lib.VARIANT_GUIDED or (s.cat_x and s.x_dim > 0)
+    c.xx = s._prep(_model_x(model, s, x), s.x_dim, "x") if need_x else None
+    for name, t in (("x", c.xx), ("y_T_mean", c.mu)):
+        if t is not None and t.shape[0] != c.N:
+            raise CardError(f"{name} has {t.shape[0]} rows, expected {c.N}")
+    c.T = int(alphas.shape[0]) if alphas is not None else None
+    c.coef = coef_on_device(alphas, omabs, c.T, s.device) if alphas is not None else None
+    c.coef0 = _coef_row0_on_device(omabs, s.device)
+    c.ws = s._workspace(c.N)
+    import ctypes as C
+
+    def filled(T, coef):
+        a = _lib.RunArgs()
+        a.struct_bytes = C.sizeof(_lib.RunArgs)
+        a.T, a.N, a.n_z, a.out_mode = T, c.N, 1, _lib.OUT_LAST
+        a.x, a.y_0_hat, a.y_T_mean, a.coef = _ptr(c.xx), _ptr(c.y0), _ptr(c.mu), _ptr(coef)
+        a.workspace, a.workspace_bytes = c.ws[1], c.ws[2]
+        return a
+
+    c.args = filled(c.T, c.coef) if alphas is not None else None
+    c.args0 = filled(1, c.coef0)
+    c.seed, c.last_t = None, -1
+    c.fn = _lib.lib().card_sampler_run
+    _step_ctx = c
+    return c
+
+
+def _step_run(c, a, y, t, noise, seed, elem_offset):
+    s = c.sampler
+    if not (y.dtype is torch.float32 and y.is_contiguous() and y.device == s.device and not y.requires_grad):
+        y = _dev_f32(y, s.device)
+    if y.dim() != 2 or y.shape[0] != c.N or y.shape[1] != s.y_dim:
+        raise CardError(f"y: expected shape ({c.N}, {s.y_dim}), got {tuple(y.shape)}")
+    out = torch.empty_like(y)
+    nz = None
+    if noise is not None:
+        nz = _dev_f32(noise, s.device)
+        if nz.numel() != c.N * s.y_dim:
+            raise CardError(f"noise: expected 1 x {c.N} x {s.y_dim} values, got {tuple(nz.shape)}")
+    a.t_hi = a.t_lo = t
+    a.y_init, a.out, a.noise = y.data_ptr(), out.data_ptr(), (nz.data_ptr() if nz is not None else None)
+    a.seed, a.elem_offset = seed & (2 ** 64 - 1), int(elem_offset)
+    if torch.cuda.current_device() == s.device.index:
+        rc = c.fn(s._h, a, _stream(s.device))
+    else:
+        with torch.cuda.device(s.device):
+            rc = c.fn(s._h, a, _stream(s.device))
+    if rc:
+        _lib.check(rc, "card_sampler_run")
+    return out
+
+
 def p_sample(model, x, y, y_0_hat, y_T_mean, t, alphas, one_minus_alphas_bar_sqrt, *, noise=None, seed=None,
              elem_offset=0):
-    """regression/diffusion_utils.py:57-90: one reverse step y_t -> y_{t-1}, t an int in [1, T-1]."""
+    """regression/diffusion_utils.py:57-90: one reverse step y_t -> y_{t-1}, t an int in [1, T-1].
+    The weights are re-checked by content on the first step of a loop (t = T - 1) and by version counters on every step;
+    between the calls of one loop the prepared arguments are reused (_StepCtx), so a call costs one launch plus a few
+    microseconds of Python.  seed=None: one seed per loop is drawn from torch's generator at t = T - 1 (the in-kernel
+    Philox stream is keyed by (seed, element, draw = T - t), so the steps of a loop get independent noise from it); a call
+    that does not continue downwards from the previous t draws a new one."""
     T = int(alphas.shape[0])
     t = int(t)
     if not 1 <= t < T:
         raise CardError(f"p_sample: t={t} outside [1, {T - 1}]")
-    # weights are re-checked by content on the first step of a loop (see sampler.py), by identity on every step
-    s = sampler_for(model, check_content=(t == T - 1))
-    coef = coef_on_device(alphas, one_minus_alphas_bar_sqrt, T, s.device)
-    seed = _fresh_seed() if (seed is None and noise is None) else int(seed or 0)
-    return s.run(_model_x(model, s, x), y_0_hat, y_T_mean, coef, T, t_hi=t, t_lo=t, y_init=y, noise=noise, seed=seed,
-                 elem_offset=elem_offset)
+    c = _step_ctx_for(model, x, y_0_hat, y_T_mean, alphas, one_minus_alphas_bar_sqrt, fresh=(t == T - 1))
+    if c.args is None:       # context created by p_sample_t_1to0 (no alphas): complete it
+        c = _step_ctx_for(model, x, y_0_hat, y_T_mean, alphas, one_minus_alphas_bar_sqrt, fresh=True)
+    if seed is None and noise is None:
+        if c.seed is None or not t < c.last_t:
+            c.seed = _fresh_seed()
+        seed = c.seed
+    c.last_t = t
+    return _step_run(c, c.args, y, t, noise, int(seed or 0), elem_offset)
 
 
 def _coef_row(one_minus_alphas_bar_sqrt, ti):
@@ -133,9 +230,15 @@ def _coef_row0_on_device(omabs, device):
 
 def p_sample_t_1to0(model, x, y, y_0_hat, y_T_mean, one_minus_alphas_bar_sqrt):
     """regression/diffusion_utils.py:94-104: the last step (timestep index 0), no noise."""
-    s = sampler_for(model, check_content=False)        # last step of a loop whose first step checked the weights
-    coef = _coef_row0_on_device(one_minus_alphas_bar_sqrt, s.device)
-    return s.run(_model_x(model, s, x), y_0_hat, y_T_mean, coef, 1, t_hi=0, t_lo=0, y_init=y)
+    c = _step_ctx
+    if not (c is not None and c.model is model and c.x is x and c.y_0_hat is y_0_hat and c.y_T_mean is y_T_mean
+            and c.omabs is one_minus_alphas_bar_sqrt):
+        # not the tail of a p_sample loop over the same objects: build a context of its own (no alphas -> t = 0 only)
+        c = _step_ctx_for(model, x, y_0_hat, y_T_mean, None, one_minus_alphas_bar_sqrt, fresh=True)
+    else:
+        c = _step_ctx_for(model, x, y_0_hat, y_T_mean, c.alphas, one_minus_alphas_bar_sqrt, fresh=False)
+    c.last_t = 0
+    return _step_run(c, c.args0, y, 0, None, 0, 0)
 
 
 def y_0_reparam(model, x, y, y_0_hat, y_T_mean, t, one_minus_alphas_bar_sqrt):
