@@ -25,8 +25,8 @@ using namespace card;
 
 namespace {
 
-constexpr int kWaves = 8;          // 2 per SIMD, one workgroup per CU
-constexpr int kThreads = kWaves * 64;
+constexpr int kWavesFull = 8;      // 2 per SIMD, one workgroup per CU
+constexpr int kWavesSmall = 4;     // small batches: 1 per SIMD, so that num_cu * 64 chains already put a tile on every SIMD
 constexpr int kTile = 16;          // chains per wave tile
 constexpr int kSlabKs = 8;         // k-steps (of 4) per slab
 constexpr int kGroupsPerWg = 8;    // tile groups (128 chains) one workgroup walks per launch
@@ -67,13 +67,18 @@ struct StreamParams {
 
 namespace {
 
-template <int H, int KS1>
-__global__ __launch_bounds__(kThreads, 2) void card_sample_stream_kernel(const StreamParams p) {
+// kWaves = 8: the full-chip form (two waves per SIMD).  kWaves = 4: the same kernel with one wave per SIMD and half as many
+// chains per workgroup, for batches of at most num_cu * 64 chains (the reference's per-minibatch calls): the 8-wave form
+// would leave half of the CUs without a workgroup there.
+template <int H, int KS1, int kWaves>
+__global__ __launch_bounds__(kWaves * 64, kWaves == 8 ? 2 : 1) void card_sample_stream_kernel(const StreamParams p) {
     using G = Geo<H>;
+    constexpr int kThreads = kWaves * 64;
     constexpr int NT = G::NT, NQ = G::NQ, NSH = G::NSH, SLAB = G::SLAB;
     constexpr int NS1 = (KS1 + kSlabKs - 1) / kSlabKs;
     constexpr int NS = NS1 + 2 * NSH;                     // slabs per timestep
-    static_assert(SLAB == NQ * kThreads * 4, "one slab = NQ b128 per thread");
+    constexpr int NST = SLAB / (kThreads * 4);            // b128 words of a slab each thread moves global -> ring
+    static_assert(SLAB == NST * kThreads * 4, "a slab is a whole number of b128 per thread");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const wbuf = lds;
     float* const tabs = lds + G::RING * SLAB;
@@ -86,17 +91,17 @@ __global__ __launch_bounds__(kThreads, 2) void card_sample_stream_kernel(const S
     // slabs come through a buffer resource with a scalar offset: no per-lane 64-bit addresses to keep (or spill)
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wimg), 0, NS * SLAB * 4, 0x00020000);
     const int voff = tid * 16;
-    f32x4 stage[NQ];          // the slab after the one being computed, on its way global -> registers -> ring
+    f32x4 stage[NST];         // the slab after the one being computed, on its way global -> registers -> ring
     auto slab_fetch = [&](int slab) {
         const int so = slab * (SLAB * 4);
 #pragma unroll
-        for (int i = 0; i < NQ; ++i)
+        for (int i = 0; i < NST; ++i)
             stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, so + i * kThreads * 16, 0));
     };
     auto stage_to_ring = [&](int buf) {
         float* dst = wbuf + buf * SLAB + tid * 4;
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) *reinterpret_cast<f32x4*>(dst + i * kThreads * 4) = stage[i];
+        for (int i = 0; i < NST; ++i) *reinterpret_cast<f32x4*>(dst + i * kThreads * 4) = stage[i];
     };
 
     // prologue: tables, gamma row of the first step, slab 0 in ring buffer 0, slab 1 in flight
@@ -347,16 +352,21 @@ int stream_ks1_for(int d_in) {
     return 0;
 }
 
-stream_kernel_t stream_kernel_for(int H, int ks1) {
-    if (H != 256) return nullptr;
+template <int W>
+stream_kernel_t stream_kernel_pick(int ks1) {
     switch (ks1) {
-        case 2: return card_sample_stream_kernel<256, 2>;
-        case 4: return card_sample_stream_kernel<256, 4>;
-        case 8: return card_sample_stream_kernel<256, 8>;
-        case 16: return card_sample_stream_kernel<256, 16>;
-        case 24: return card_sample_stream_kernel<256, 24>;
+        case 2: return card_sample_stream_kernel<256, 2, W>;
+        case 4: return card_sample_stream_kernel<256, 4, W>;
+        case 8: return card_sample_stream_kernel<256, 8, W>;
+        case 16: return card_sample_stream_kernel<256, 16, W>;
+        case 24: return card_sample_stream_kernel<256, 24, W>;
         default: return nullptr;
     }
+}
+
+stream_kernel_t stream_kernel_for(int H, int ks1, int waves) {
+    if (H != 256) return nullptr;
+    return waves == kWavesFull ? stream_kernel_pick<kWavesFull>(ks1) : stream_kernel_pick<kWavesSmall>(ks1);
 }
 
 }  // namespace
@@ -370,7 +380,7 @@ bool stream_supports(const card_model_desc* d, int d_in) {
 int stream_create(card_sampler* s, const card_model_desc* d, hipStream_t stream) {
     const int H = d->hidden, d_in = s->d_in;
     const int ks1 = stream_ks1_for(d_in);
-    stream_kernel_t kern = stream_kernel_for(H, ks1);
+    stream_kernel_t kern = stream_kernel_for(H, ks1, kWavesFull);
     if (!kern) return card_fail(CARD_E_UNSUPPORTED, "card_sampler_create: no streamed kernel for hidden=%d d_in=%d", H, d_in);
     const int ns1 = (ks1 + kSlabKs - 1) / kSlabKs, NSH = H / 32, SLAB = kSlabKs * (H / 16) * 64;
     s->k1 = ks1;
@@ -380,6 +390,7 @@ int stream_create(card_sampler* s, const card_model_desc* d, hipStream_t stream)
     HIP_TRY(hipMalloc(&s->w1s, (size_t)(4 * H + 4) * sizeof(float)));
     HIP_TRY(hipMalloc(&s->gtab, (size_t)d->n_embed * 3 * H * sizeof(float)));
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)stream_kernel_for(H, ks1, kWavesSmall), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
     stream_pack_kernel<<<512, 256, 0, stream>>>(d->W[0], d->W[1], d->W[2], H, d_in, ns1, s->wpk);
     stream_tabs_kernel<<<1, 256, 0, stream>>>(d->b[0], d->b[1], d->b[2], d->W4, d->b4, H, s->w1s);
     stream_gamma_kernel<<<512, 256, 0, stream>>>(d->gamma[0], d->gamma[1], d->gamma[2], d->n_embed, H, s->gtab);
@@ -402,17 +413,23 @@ int stream_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     p.T = r.T; p.t_hi = r.t_hi; p.t_lo = r.t_lo;
     p.x_dim = s->x_dim; p.cat_x = s->cat_x; p.cat_y_pred = s->cat_y_pred;
     p.out_mode = r.out_mode; p.eps_only = r.eps_only; p.n_z = r.n_z;
-    stream_kernel_t kern = reinterpret_cast<stream_kernel_t>(s->kernel);
+    // Small batches (at most num_cu * 4 waves * 16 chains = 16 384 on 256 CUs): four waves per workgroup, one per SIMD,
+    // so every SIMD of the chip gets a tile; the 8-wave form would run them on half of the CUs.  CARD_AMD_STREAM_SMALL=0
+    // keeps the 8-wave form (A/B); results are identical (same per-chain arithmetic).
+    const bool small_ok = !(getenv("CARD_AMD_STREAM_SMALL") && getenv("CARD_AMD_STREAM_SMALL")[0] == '0');
+    const bool small = small_ok && p.N <= (long long)s->num_cu * kWavesSmall * kTile;
+    const int waves = small ? kWavesSmall : kWavesFull;
+    stream_kernel_t kern = small ? stream_kernel_for(s->hidden, s->k1, kWavesSmall) : reinterpret_cast<stream_kernel_t>(s->kernel);
     // launches of at most num_cu workgroups x kGroupsPerWg groups x 128 chains: every workgroup walks the same
     // number of groups (the kernel's barriers need that) and one launch stays well under a second
-    const long long group = kWaves * kTile;
+    const long long group = waves * kTile;
     const long long chunk = (long long)s->num_cu * kGroupsPerWg * group;
     for (long long b = 0; b < p.N; b += chunk) {
         p.n_begin = b;
         p.n_end = b + chunk < p.N ? b + chunk : p.N;
         const long long groups = (p.n_end - p.n_begin + group - 1) / group;
         const long long grid = groups < s->num_cu ? groups : s->num_cu;
-        kern<<<dim3((unsigned)grid), dim3(kThreads), s->lds_bytes, stream>>>(p);
+        kern<<<dim3((unsigned)grid), dim3(waves * 64), s->lds_bytes, stream>>>(p);
         HIP_TRY(hipGetLastError());
     }
     return CARD_OK;

@@ -23,6 +23,14 @@ def cuda(t):
     return t.to(DEV)
 
 
+@pytest.fixture(params=["small4", "full8"], autouse=True)
+def wave_form(request, monkeypatch):
+    """Batches of at most num_cu * 64 chains run with four waves per workgroup (one per SIMD) by default;
+    CARD_AMD_STREAM_SMALL=0 (read per call) keeps the 8-wave form.  Every test runs against both."""
+    monkeypatch.setenv("CARD_AMD_STREAM_SMALL", "1" if request.param == "small4" else "0")
+    return request.param
+
+
 def _case(x_dim, T, N, seed, cat_x=True, cat_y_pred=True):
     sd = guided_state_dict(x_dim, T, seed, hidden=256, cat_x=cat_x, cat_y_pred=cat_y_pred)
     gen = torch.Generator().manual_seed(seed + 1)
@@ -119,3 +127,16 @@ def test_stream_kernel_several_launches():
     b = sg.run(cuda(x), cuda(y0), cuda(mu), coef, T, seed=4, n_z=n_z)
     assert a.shape == (rows * n_z, 1) and torch.isfinite(a).all()
     assert norm_rel_err(a.cpu(), b.cpu()) <= TOL
+
+
+@pytest.mark.parametrize("N", [64, 1000, 16384])
+def test_four_wave_and_eight_wave_forms_agree_bit_for_bit(N, monkeypatch):
+    T = 7
+    sd, x, y0, mu, _, alphas, omabs = _case(13, T, N, 77)
+    s = Sampler.from_state_dict(sd, device=DEV)
+    coef = cuda(make_coef_table(alphas, omabs))
+    outs = []
+    for small in ("1", "0"):
+        monkeypatch.setenv("CARD_AMD_STREAM_SMALL", small)
+        outs.append(s.run(cuda(x), cuda(y0), cuda(mu), coef, T, seed=3, out_mode=_lib.OUT_ALL))
+    assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0]).all()
