@@ -70,6 +70,9 @@ struct GuidedParams {
     const float* w1s;     // (4, nqs, 64, 4): W1[32j + (l&31)][1 + 8q + 2e + (l>>5)]
     float* ws;            // grid * 8 waves * 4096 floats
     int nqs;              // ceil((d_in - 1) / 8)
+    // time-sliced cooperative launches (card_sample_coop2_kernel): this launch is slice sl_k of sl_K
+    int sl_k, sl_K, sl_nsingle, sl_S, sl_L;
+    float* ybuf;          // (N) chain states handed from one slice to the next
 };
 
 
@@ -591,6 +594,217 @@ __global__ __launch_bounds__(kCoopThreads, 2) void card_sample_coop_kernel(const
 }
 
 // ------------------------------------------------------------------------------------------------
+// Between one and two tiles per CU: the paired cooperative form, time-sliced.
+// With 256 < n_tiles < 512 (12 800 chains = the reference's Year minibatch, regression/configs/uci_year.yml:62,67) the
+// kernel above puts two workgroups on some CUs and one on the others; a CU with two tiles needs ~9.1 us per timestep,
+// one with a single tile ~5.3 us, so the singles idle for 40 % of the launch.  Here a workgroup is TWO cooperative
+// groups ("halves", 4 waves each, one workgroup per CU, so which tiles share a CU is the kernel's choice and not the
+// dispatcher's), and the loop is cut into sl_K launches ("slices").  In slice k the tiles [k * n_single, (k+1) * n_single)
+// run alone on a CU (half 1 of their workgroup only keeps the barriers company) and advance L timesteps, every other tile
+// shares a CU and advances S < L timesteps, with L * 5.3 us = S * 9.1 us: every CU is busy for the whole slice.  Each
+// tile is "single" in exactly one slice, so after sl_K slices every chain has done (sl_K - 1) * S + L = all its
+// timesteps.  Between slices a chain's state is one float in ybuf (stream order is the only synchronisation); the
+// arithmetic per chain and timestep is the kernel's above, so results are bit-identical.  sl_K = 1 (S = L) is the
+// un-sliced paired form.
+// ------------------------------------------------------------------------------------------------
+constexpr int kCoop2Threads = 2 * kCoopThreads;
+constexpr int kHalfLdsFloats = 2 * kTileM * kExLd + kCoopWaves * kTileM + 2 * kGammaRow;
+constexpr int kCoop2LdsFloats = 2 * kHalfLdsFloats + kTabFloats;
+
+__global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop2_kernel(const RunParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave >> 2, w = wave & 3;
+    const int htid = tid & (kCoopThreads - 1);                     // thread index inside the half
+    float* const ex = lds + half * kHalfLdsFloats;                 // 2 exchange tiles [32][132]
+    float* const red = ex + 2 * kTileM * kExLd;                    // [4][32] lin4 partial sums
+    float* const gsl = red + kCoopWaves * kTileM;                  // 2 gamma rows
+    float* const tab = lds + 2 * kHalfLdsFloats;                   // small tables, shared by the halves
+    const int m = lane & 31, hh = lane >> 5;
+    for (int i = tid; i < kTabFloats; i += kCoop2Threads) tab[i] = p.wpk[kOffB + i];
+
+    // ---- which tile this half advances in this slice, from where, and how far
+    const long long n_tiles = (p.n_end - p.n_begin + kTileM - 1) / kTileM;
+    const int k = p.sl_k, nsg = p.sl_nsingle;
+    const long long first_single = (long long)k * nsg;
+    long long n_s = n_tiles - first_single;
+    n_s = n_s < 0 ? 0 : (n_s > nsg ? nsg : n_s);                   // tiles that run alone in this slice
+    long long tile = -1;
+    int quota = 0;
+    if ((long long)blockIdx.x < n_s) {
+        if (half == 0) { tile = first_single + blockIdx.x; quota = p.sl_L; }
+    } else {
+        const long long j = 2 * ((long long)blockIdx.x - n_s) + half;
+        if (j < n_tiles - n_s) { tile = j < first_single ? j : j + n_s; quota = p.sl_S; }
+    }
+    // every wave of the workgroup walks the same number of barrier rounds: those of half 0 (never fewer than half 1's)
+    const int n_iter = (long long)blockIdx.x < n_s ? p.sl_L : p.sl_S;
+    const bool active = tile >= 0;
+    const int before = k * p.sl_S + ((active && tile / nsg < k) ? p.sl_L - p.sl_S : 0);
+    const int th = p.t_hi - before;                                // first timestep of this slice for this tile
+    const bool first_seg = before == 0, last_seg = th - quota + 1 <= p.t_lo;
+
+    float A2[64], A3[64];
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p.wpk + kOffW2 + ((w * 16 + i) * 64 + lane) * 4);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p.wpk + kOffW3 + ((w * 16 + i) * 64 + lane) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { A2[4 * i + e] = a[e]; A3[4 * i + e] = b[e]; }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) { A2[i] = 0.0f; A3[i] = 0.0f; }
+    }
+    __syncthreads();
+    const float* const tb = tab + 4 * hh;
+    const float* const w4l = tab + (kOffW4 - kOffB) + 32 * w + 4 * hh;
+    const float b4 = tab[kOffB4 - kOffB];
+    const float a10 = hh == 0 ? tab[(kOffW1 - kOffB) + 32 * w + m] : 0.0f;
+    float* const exw = ex + m * kExLd + 32 * w + 4 * hh;
+    const float* const exr = ex + m * kExLd + 4 * hh;
+    const int T = p.T;
+    const int draw0 = p.y_init ? (T - p.t_hi) : 0;
+    const int slot_base = draw0;
+
+    const long long row = p.n_begin + (active ? tile : 0) * kTileM + m;
+    const bool valid = active && row < p.n_end;
+    const long long rc = row < p.n_end ? row : p.n_end - 1;
+    const long long rr = p.n_z > 1 ? rc / p.n_z : rc;
+    const float mu = p.ytmean[rr];
+    const float y0h = p.y0hat[rr];
+    const unsigned long long elem = p.elem_offset + (unsigned long long)rc;
+    auto static_feature = [&](int kk) -> float {
+        if (p.cat_y_pred && kk == 1) return y0h;
+        const int xi = kk - 1 - (p.cat_y_pred ? 1 : 0);
+        return (p.cat_x && xi < p.x_dim) ? p.x[rr * p.x_dim + xi] : 0.0f;
+    };
+    f32x16 c1;
+    load_bias(c1, tb, w);
+    if (active) {
+        for (int q = 0; q < p.nqs; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p.w1s + ((long long)(w * p.nqs + q) * 64 + lane) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], static_feature(1 + 8 * q + 2 * e + hh), c1, 0, 0, 0);
+        }
+    }
+    float zc[4];
+    uint32_t zblock = 0xFFFFFFFFu;
+    auto draw = [&](int d) -> float {
+        if (p.noise) return p.noise[(long long)(d - draw0) * p.N + rc];
+        const uint32_t blk = (uint32_t)d >> 2;
+        if (blk != zblock) {
+            philox_normal4(p.seed, elem, blk, zc);
+            zblock = blk;
+        }
+        return pick4(zc, d & 3);
+    };
+    auto store_state = [&](int s, float v) {
+        long long slot;
+        if (p.out_mode == CARD_OUT_ALL) slot = s - slot_base;
+        else if (p.out_mode == CARD_OUT_SELECT) slot = p.state_slot[s];
+        else return;
+        if (slot >= 0 && valid && hh == 0 && w == 0) p.out[slot * p.N + row] = v;
+    };
+    float y = 0.0f;
+    if (active) {
+        if (!first_seg) {
+            y = p.ybuf[rc];
+        } else if (p.y_init) {
+            y = p.y_init[rc];
+        } else {
+            y = draw(0) + mu;                                 // diffusion_utils.py:109-110
+            store_state(0, y);
+        }
+        for (int i = htid; i < kGammaRow; i += kCoopThreads) gsl[i] = p.gtab[(long long)th * kGammaRow + i];
+    }
+    __syncthreads();
+    int gcur = 0;
+
+    auto publish = [&](const f32x16& a, int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {a[4 * q + 0], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+            *reinterpret_cast<f32x4*>(exw + buf * kTileM * kExLd + 8 * q) = v;
+        }
+    };
+    auto hidden = [&](const float (&A)[64], int buf, int layer, const float* gl) -> f32x16 {
+        f32x16 acc;
+        load_bias(acc, tb + layer * kH, w);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const f32x4 h = lds4(exr + buf * kTileM * kExLd + 32 * (i >> 2) + 8 * (i & 3));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * i + e], h[e], acc, 0, 0, 0);
+        }
+        epilogue_tile(acc, gl + layer * kH, w);
+        return acc;
+    };
+
+    for (int it = 0; it < n_iter; ++it) {
+        const bool on = active && it < quota;                 // uniform per wave
+        const int t = th - it;
+        const bool more = on && it + 1 < quota;
+        f32x4 gn = {0.f, 0.f, 0.f, 0.f};
+        float z = 0.0f;
+        f32x16 acc;
+        const float* const gl = gsl + gcur * kGammaRow + 4 * hh;
+        if (on) {
+            if (more && htid < kGammaRow / 4) gn = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(t - 1) * kGammaRow + htid * 4);
+            z = t >= 1 && !p.eps_only ? draw(T - t) : 0.0f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a10, hh == 0 ? y : 0.0f, c1, 0, 0, 0);
+            epilogue_tile(acc, gl, w);
+            publish(acc, 0);
+        }
+        __syncthreads();
+        if (on) {
+            acc = hidden(A2, 0, 1, gl);
+            publish(acc, 1);
+        }
+        __syncthreads();
+        if (on) {
+            acc = hidden(A3, 1, 2, gl);
+            if (more && htid < kGammaRow / 4) *reinterpret_cast<f32x4*>(gsl + (gcur ^ 1) * kGammaRow + htid * 4) = gn;
+            float part = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 wv = lds4(w4l + 8 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part = fmaf(acc[4 * q + e], wv[e], part);
+            }
+            part += __shfl_xor(part, 32, 64);
+            if (hh == 0) red[w * kTileM + m] = part;
+        }
+        __syncthreads();
+        if (on) {
+            const float eps = (((red[m] + red[kTileM + m]) + red[2 * kTileM + m]) + red[3 * kTileM + m]) + b4;
+            gcur ^= more ? 1 : 0;
+            if (p.eps_only) {
+                if (valid && hh == 0 && w == 0) p.out[row] = eps;
+            } else {
+                const float* c = p.coef + (long long)t * CARD_COEF_COLS;
+                const float y0r = c[CARD_COEF_INV_SQRT_AB] * ((y - c[CARD_COEF_ONE_M_SQRT_AB] * mu) - eps * c[CARD_COEF_SOMAB]);
+                if (t >= 1) {
+                    const float yh = (c[CARD_COEF_G0] * y0r + c[CARD_COEF_G1] * y) + c[CARD_COEF_G2] * mu;
+                    y = yh + c[CARD_COEF_SIGMA] * z;
+                } else {
+                    y = y0r;
+                }
+                store_state(T - t, y);
+            }
+        }
+    }
+    if (valid && hh == 0 && w == 0 && !p.eps_only) {
+        if (!last_seg) p.ybuf[row] = y;
+        else if (p.out_mode == CARD_OUT_LAST) p.out[row] = y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // create-time packing kernels
 // ------------------------------------------------------------------------------------------------
 // A-operand fragment order of a 128x128 layer: element e of lane l in block (j, jj, q) is
@@ -693,6 +907,8 @@ int guided_create(card_sampler* s, const card_model_desc* d, hipStream_t stream)
                                                              (size_t)kCoopLdsFloats * sizeof(float)));
         s->coop_blocks = nb < 1 ? 1 : (nb > 2 ? 2 : nb);
         s->coop_force = (cv && cv[0] == '2') ? 1 : 0;     // CARD_AMD_COOP=2: cooperative kernel for every batch size (A/B)
+        HIP_TRY(hipFuncSetAttribute((const void*)card_sample_coop2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(kCoop2LdsFloats * sizeof(float))));
     }
     pack_hidden_kernel<<<kH * kH / 256, 256, 0, stream>>>(d->W[1], kLn2, s->wpk + kOffW2);
     pack_hidden_kernel<<<kH * kH / 256, 256, 0, stream>>>(d->W[2], kLn2, s->wpk + kOffW3);
@@ -744,6 +960,36 @@ int guided_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     if (s->coop_blocks > 0 && (s->coop_force || tiles_total <= 7LL * s->num_cu)) {
         p.n_begin = 0;
         p.n_end = p.N;
+        // Between one and two tiles per CU (the reference's Year minibatch: 12 800 chains = 400 tiles): the time-sliced
+        // paired form, see card_sample_coop2_kernel.  n_single CUs' worth of tiles run alone in each slice; every tile
+        // does so in exactly one of the K slices.  rho = the measured cost ratio of a timestep on a shared CU (9.1 us
+        // for its two tiles) to one on a CU of its own (5.3 us): tools/bench_small.py.  CARD_AMD_COOP2=0: off (A/B).
+        const char* c2 = getenv("CARD_AMD_COOP2");
+        const int n_steps = p.t_hi - p.t_lo + 1;
+        if (s->coop_blocks == 2 && !(c2 && c2[0] == '0') && !p.eps_only && tiles_total > s->num_cu &&
+            tiles_total < 2LL * s->num_cu && n_steps >= 64 && p.ws) {
+            double rho = 1.717;
+            if (const char* rv = getenv("CARD_AMD_COOP2_RHO")) rho = atof(rv) > 1.0 ? atof(rv) : rho;     // tuning runs
+            const long long n_single = 2LL * s->num_cu - tiles_total;
+            const int K = (int)((tiles_total + n_single - 1) / n_single);
+            const int S = (int)((double)n_steps / ((double)(K - 1) + rho) + 0.5);
+            const int L = n_steps - (K - 1) * S;
+            const unsigned long long need = (unsigned long long)p.N * sizeof(float);
+            const bool fits = !r.lib_scratch || need <= r.workspace_bytes;       // (the sampler's own slots always do)
+            if (K <= 8 && S >= 8 && L >= S && fits) {
+                p.ybuf = p.ws;
+                p.sl_K = K; p.sl_nsingle = (int)n_single; p.sl_S = S; p.sl_L = L;
+                for (int k = 0; k < K; ++k) {
+                    long long n_s = tiles_total - (long long)k * n_single;
+                    n_s = n_s > n_single ? n_single : n_s;
+                    const long long grid = n_s + (tiles_total - n_s + 1) / 2;
+                    p.sl_k = k;
+                    card_sample_coop2_kernel<<<dim3((unsigned)grid), dim3(kCoop2Threads), (size_t)kCoop2LdsFloats * sizeof(float), stream>>>(p);
+                    HIP_TRY(hipGetLastError());
+                }
+                return CARD_OK;
+            }
+        }
         const long long cap = (long long)s->num_cu * s->coop_blocks;
         const long long grid = tiles_total < cap ? tiles_total : cap;
         card_sample_coop_kernel<<<dim3((unsigned)grid), dim3(kCoopThreads), (size_t)kCoopLdsFloats * sizeof(float), stream>>>(p);

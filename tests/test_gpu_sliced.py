@@ -1,0 +1,80 @@
+"""The time-sliced paired cooperative kernel (card_sample_coop2_kernel, card_guided.hip): between one and two 32-chain
+tiles per CU (the reference's Year minibatch, 64 rows x 200 z = 12 800 chains, regression/configs/uci_year.yml:62,67)
+the loop is cut into slices in which every CU is busy, with chain states handed over in global memory between the
+launches.  Bar: bit-identical to the un-sliced kernels (CARD_AMD_COOP2=0) in every output mode, and within 1e-4 of the
+oracle under injected noise on slices of the batch."""
+import pytest
+import torch
+
+from card_amd import _lib
+from card_amd.sampler import Sampler, make_coef_table
+from oracle import card_oracle as orc
+from tests.helpers import load_golden, norm_rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-4
+
+
+def _tiles_per_cu(N):
+    cu = torch.cuda.get_device_properties(0).multi_processor_count
+    return (N + 31) // 32 / cu
+
+
+def _inputs(g, rows, seed):
+    gen = torch.Generator().manual_seed(seed)
+    x_dim = g["x"].shape[1]
+    x = torch.randn(rows, x_dim, generator=gen)
+    y0 = torch.randn(rows, 1, generator=gen)
+    mu = y0 + 0.1 * torch.randn(rows, 1, generator=gen)
+    return x.to(DEV), y0.to(DEV), mu.to(DEV)
+
+
+@pytest.mark.parametrize("N", [12800, 9001, 8224, 14336])
+def test_sliced_equals_unsliced_bit_for_bit(N, monkeypatch):
+    assert 1.0 < _tiles_per_cu(N) < 2.0, "sized for a 256-CU MI355X"
+    g = load_golden("reg_boston_T1000")
+    s = Sampler.from_state_dict(g["sd"], device=DEV)
+    T = 200                                   # the first 200 timesteps' schedule rows of the T = 1000 model
+    coef = make_coef_table(g["alphas"][:T], g["omabs"][:T]).to(DEV)
+    x, y0, mu = _inputs(g, N, 3)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CARD_AMD_COOP2", mode)
+        last = s.run(x, y0, mu, coef, T, seed=21, elem_offset=7)
+        sel = s.run(x, y0, mu, coef, T, seed=21, elem_offset=7, out_mode=_lib.OUT_SELECT, states=[0, 1, 57, 58, 120, T - 1, T])
+        # a segment that starts in the middle of the loop from a given state (p_sample_loop_with_eval's segments)
+        seg = s.run(x, y0, mu, coef, T, seed=21, elem_offset=7, t_hi=150, t_lo=20, y_init=sel[2])
+        outs[mode] = (last, sel, seg)
+    for a, b in zip(outs["1"], outs["0"]):
+        assert torch.equal(a, b) and torch.isfinite(a).all()
+    assert torch.equal(outs["1"][0], outs["1"][1][-1])
+    # the entry point that allocates nothing takes the hand-over buffer from the library's static array
+    monkeypatch.setenv("CARD_AMD_COOP2", "1")
+    assert torch.equal(s.run(x, y0, mu, coef, T, seed=21, elem_offset=7, static_scratch=True), outs["0"][0])
+
+
+def test_sliced_full_trajectory_and_row_tiling_vs_oracle(monkeypatch):
+    """OUT_ALL with injected noise, rows tiled in-kernel (64 rows x 200 z like uci_year.yml): every state equals the
+    un-sliced run bit for bit, and the chains of the first and last rows match the oracle."""
+    g = load_golden("reg_year_T1000")
+    s = Sampler.from_state_dict(g["sd"], device=DEV)
+    T, rows, n_z = 80, 64, 200
+    alphas, _, omabs = orc.make_schedule("linear", T, 1e-4, 0.25)
+    coef = make_coef_table(alphas, omabs).to(DEV)
+    x, y0, mu = _inputs(g, rows, 5)
+    N = rows * n_z
+    noise = torch.randn(T, N, 1, generator=torch.Generator().manual_seed(9))
+    outs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CARD_AMD_COOP2", mode)
+        outs.append(s.run(x, y0, mu, coef, T, noise=noise.to(DEV), out_mode=_lib.OUT_ALL, n_z=n_z))
+    assert torch.equal(outs[0], outs[1])
+    w = g["weights"]
+    for r in (0, rows - 1):
+        sl = slice(r * n_z, r * n_z + 40)
+        tile = lambda t: t[r:r + 1].cpu().repeat(40, 1)
+        want = torch.stack(orc.p_sample_loop(w, tile(x), tile(y0), tile(mu), T, alphas, omabs, noise[:, sl]), 0)
+        err = max(norm_rel_err(outs[0][k, sl].cpu(), want[k]) for k in range(T + 1))
+        print(f"sliced kernel, row {r}: worst per-state norm-rel err vs oracle {err:.2e}")
+        assert err <= TOL
