@@ -192,8 +192,15 @@ def main():
             launches = math.ceil(N / chunk) * a.steps
             kernel = "card_sample_guided_kernel" if H == 128 else "card_sample_stream_kernel"
         elif cls_coop:
+            # clscoop_run(): one launch up to num_cu tiles, else round-robin time slices of num_cu x 2 (tile, segment) slots
+            cu = torch.cuda.get_device_properties(dev).multi_processor_count
             chunk = None
-            launches = a.steps
+            tiles, P = math.ceil(N / 32), 2 * cu
+            n_seg = 1
+            if tiles > P and T >= 64:
+                n_seg = min(range(1, 17), key=lambda ns: (math.ceil(tiles * ns / P) * (math.ceil(T / ns) + 4.0)) if T // ns >= 32 else float("inf"))
+            per = P if n_seg > 1 else min(tiles, P)
+            launches = (1 if tiles <= cu else math.ceil(tiles * n_seg / per)) * a.steps
             kernel = "card_sample_cls_coop_kernel"
         else:
             # GEMM back end: a timestep is 4 GEMM launches + 1 update launch per chunk of chains; the two F x F

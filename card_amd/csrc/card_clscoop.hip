@@ -30,7 +30,10 @@ constexpr int kExLd = kF + 4;      // activation exchange row stride (floats)
 constexpr int kYLd = kCmax + 4;    // ys / partial-tile row stride
 constexpr int kGRow = 3 * kF;
 constexpr int kTab = 6 * kF + kCmax;                 // b1|b2|b3 | shift1|shift2|shift3 (log2 units) | b4
-constexpr int kLdsFloats = 2 * kTileM * kExLd + kTileM * kYLd + kWaves * kTileM * kYLd + 2 * kGRow + kTab;
+constexpr int kTileLdsFloats = 2 * kTileM * kExLd + kTileM * kYLd + kWaves * kTileM * kYLd + 2 * kGRow;   // per tile position
+constexpr int kGmax = 2;                             // tile positions per workgroup
+constexpr long long kChunkTiles = 8192;              // tiles per sliced chunk: bounds the hand-over buffer (262 144 chains)
+__host__ __device__ constexpr int lds_floats(int G) { return G * kTileLdsFloats + kTab; }
 constexpr int kPrioValu = 3, kPrioMfma = 0;
 
 }  // namespace
@@ -54,6 +57,11 @@ struct ClsCoopParams {
     int T, t_hi, t_lo;
     int C, nq1, guidance;
     int out_mode, eps_only, n_z;
+    // time slicing (see the kernel): this launch covers chains [n_begin, n_end) and runs the slots [q0, q1); slot q is
+    // segment q / n_tiles of tile q % n_tiles, the call's timesteps being cut into n_seg segments
+    long long n_begin, n_end, q0, q1;
+    int n_seg, g_eff;
+    float* ybuf;          // (n_end - n_begin, C) chain states between the segments of a tile
 };
 
 namespace {
@@ -83,13 +91,23 @@ __device__ __forceinline__ void epilogue_bn(f32x16& acc, const float* gl, const 
     __builtin_amdgcn_s_setprio(kPrioMfma);
 }
 
+// One workgroup = four waves (one per SIMD, up to 512 registers each) that advance G tiles in lockstep with ONE copy of
+// the weight fragments in registers.  G = 2 is what keeps a CU's matrix pipes busy: while the waves wait at a barrier
+// for one tile's exchange, there is nothing else to run (a second workgroup does not fit: 2 x 128 weight registers
+// per lane), so the second tile's work between the same barriers halves the barrier stalls per tile-timestep.
+//
+// Time slicing.  A tile is NOT tied to a workgroup for the whole loop: the timesteps of a call are cut into n_seg
+// segments and the (tile, segment) pairs are laid out as slots q = segment * n_tiles + tile; one launch ("slice") runs
+// num_cu * G consecutive slots, one per tile position of every workgroup, so every slice fills the chip whatever
+// n_tiles is (250 images x 100 z = 782 tiles used to cost four rounds of 256 tiles, the last one with 14).  A tile's
+// segments land in different slices in order (n_tiles >= slots per slice when slicing is on), stream order is the only
+// synchronisation, and a chain's state travels through ybuf.  The arithmetic per chain and timestep does not depend
+// on G or on the slicing: results are bit-identical to the one-tile, un-sliced form.
+template <int G>
 __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const ClsCoopParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* const ex = lds;                                   // 2 x [32][132] activations
-    float* const ys = ex + 2 * kTileM * kExLd;               // [32][36] y_t, chain-major
-    float* const red = ys + kTileM * kYLd;                   // [4][32][36] lin4 partial tiles
-    float* const gsl = red + kWaves * kTileM * kYLd;         // 2 gamma rows
-    float* const tab = gsl + 2 * kGRow;
+    constexpr int kTileLds = 2 * kTileM * kExLd + kTileM * kYLd + kWaves * kTileM * kYLd + 2 * kGRow;
+    float* const tab = lds + G * kTileLds;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -117,34 +135,95 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
     __syncthreads();
     const float* const tb = tab + 32 * w + 4 * hh;                      // bias of this wave's features: + layer*128 + 8q
     const float* const ts = tab + 3 * kF + 32 * w + 4 * hh;             // shift
-    float* const exw = ex + m * kExLd + 32 * w + 4 * hh;
-    const float* const exr = ex + m * kExLd + 4 * hh;
     const int c0 = 8 * w + 4 * hh;                                       // first of the 4 classes this lane updates
-    float* const ysw = ys + m * kYLd + c0;
-    const float* const ysr = ys + m * kYLd + 4 * hh;
     const f32x4 b4v = lds4(tab + 6 * kF + c0);
 
-    const long long n_tiles = (p.N + kTileM - 1) / kTileM;
+    const long long n_tiles = (p.n_end - p.n_begin + kTileM - 1) / kTileM;
     const int T = p.T;
     const int draw0 = p.y_init ? (T - p.t_hi) : 0;
     const int slot_base = draw0;
     const long long NC = p.N * C;
-    int gcur = 0;
+    const int n_steps = p.t_hi - p.t_lo + 1;
 
-    for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const long long row = tile * kTileM + m;
-        const bool valid = row < p.N;
-        const long long rc = valid ? row : p.N - 1;
-        const long long rr = p.n_z > 1 ? rc / p.n_z : rc;
-        // hoisted static part of layer 1 and this wave's x_feat block
-        f32x16 c1, xf;
+    // ---- the G tile positions of this workgroup
+    float* ex[G]; float* ys[G]; float* red[G]; float* gsl[G];
+    float* exw[G]; const float* exr[G]; float* ysw[G]; const float* ysr[G];
+    bool active[G], valid[G], first_seg[G], last_seg[G];
+    long long row[G], rc[G], rr[G];
+    int th[G], cnt[G], gcur[G];
+    f32x16 c1[G], xf[G];
+    float yv[G][4], mu[G][4], zc[G][4][4];
+    uint32_t zblock[G];
+    int n_iter = 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float* base = lds + g * kTileLds;
+        ex[g] = base;                                        // 2 x [32][132] activations
+        ys[g] = ex[g] + 2 * kTileM * kExLd;                  // [32][36] y_t, chain-major
+        red[g] = ys[g] + kTileM * kYLd;                      // [4][32][36] lin4 partial tiles
+        gsl[g] = red[g] + kWaves * kTileM * kYLd;            // 2 gamma rows
+        exw[g] = ex[g] + m * kExLd + 32 * w + 4 * hh;
+        exr[g] = ex[g] + m * kExLd + 4 * hh;
+        ysw[g] = ys[g] + m * kYLd + c0;
+        ysr[g] = ys[g] + m * kYLd + 4 * hh;
+        const long long q = p.q0 + (long long)blockIdx.x * p.g_eff + g;
+        active[g] = g < p.g_eff && q < p.q1;
+        const long long tile = active[g] ? q % n_tiles : 0;
+        const int seg = active[g] ? (int)(q / n_tiles) : 0;
+        const int s0 = (int)((long long)n_steps * seg / p.n_seg), s1 = (int)((long long)n_steps * (seg + 1) / p.n_seg);
+        th[g] = p.t_hi - s0;
+        cnt[g] = active[g] ? s1 - s0 : 0;
+        first_seg[g] = seg == 0;
+        last_seg[g] = seg == p.n_seg - 1;
+        n_iter = cnt[g] > n_iter ? cnt[g] : n_iter;
+        row[g] = p.n_begin + tile * kTileM + m;
+        valid[g] = active[g] && row[g] < p.n_end;
+        rc[g] = row[g] < p.n_end ? row[g] : p.n_end - 1;
+        rr[g] = p.n_z > 1 ? rc[g] / p.n_z : rc[g];
+        gcur[g] = 0;
+        zblock[g] = 0xFFFFFFFFu;
+    }
+    // every wave of the workgroup must walk the same number of barrier rounds
+    n_iter = __builtin_amdgcn_readfirstlane(n_iter);
+
+    auto draw = [&](int g, int d, float (&z)[4]) {
+        if (p.noise) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) z[k] = c0 + k < C ? p.noise[(long long)(d - draw0) * NC + rc[g] * C + c0 + k] : 0.0f;
+            return;
+        }
+        const uint32_t blk = (uint32_t)d >> 2;
+        if (blk != zblock[g]) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                philox_normal4(p.seed, p.elem_offset + (unsigned long long)(rc[g] * C + (c0 + k < C ? c0 + k : 0)), blk, zc[g][k]);
+            zblock[g] = blk;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) z[k] = pick4(zc[g][k], d & 3);
+    };
+    auto store_state = [&](int g, int s) {
+        long long slot;
+        if (p.out_mode == CARD_OUT_ALL) slot = s - slot_base;
+        else if (p.out_mode == CARD_OUT_SELECT) slot = p.state_slot[s];
+        else return;
+        if (slot < 0 || !valid[g]) return;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (c0 + k < C) p.out[slot * NC + row[g] * C + c0 + k] = yv[g][k];
+    };
+
+    // ---- per-tile prologue: hoisted static part of layer 1, this wave's x_feat block, the chain state
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (!active[g]) continue;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 b = lds4(tb + 8 * q);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                c1[4 * q + k] = b[k];
-                xf[4 * q + k] = p.xfeat[rr * kF + 32 * w + 8 * q + 4 * hh + k];
+                c1[g][4 * q + k] = b[k];
+                xf[g][4 * q + k] = p.xfeat[rr[g] * kF + 32 * w + 8 * q + 4 * hh + k];
             }
         }
         if (p.guidance) {
@@ -153,105 +232,97 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int c = 8 * q + 4 * hh + e;
-                    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], c < C ? p.y0hat[rr * C + c] : 0.0f, c1, 0, 0, 0);
+                    c1[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], c < C ? p.y0hat[rr[g] * C + c] : 0.0f, c1[g], 0, 0, 0);
                 }
             }
         }
-        // the 4 (chain, class) elements this lane owns
-        float yv[4], mu[4], zc[4][4];
-        uint32_t zblock = 0xFFFFFFFFu;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) mu[k] = c0 + k < C ? p.ytmean[rr * C + c0 + k] : 0.0f;
-        auto draw = [&](int d, float (&z)[4]) {
-            if (p.noise) {
+        for (int k = 0; k < 4; ++k) mu[g][k] = c0 + k < C ? p.ytmean[rr[g] * C + c0 + k] : 0.0f;
+        if (!first_seg[g]) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) z[k] = c0 + k < C ? p.noise[(long long)(d - draw0) * NC + rc * C + c0 + k] : 0.0f;
-                return;
-            }
-            const uint32_t blk = (uint32_t)d >> 2;
-            if (blk != zblock) {
+            for (int k = 0; k < 4; ++k) yv[g][k] = c0 + k < C ? p.ybuf[(rc[g] - p.n_begin) * C + c0 + k] : 0.0f;
+        } else if (p.y_init) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    philox_normal4(p.seed, p.elem_offset + (unsigned long long)(rc * C + (c0 + k < C ? c0 + k : 0)), blk, zc[k]);
-                zblock = blk;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) z[k] = pick4(zc[k], d & 3);
-        };
-        auto store_state = [&](int s) {
-            long long slot;
-            if (p.out_mode == CARD_OUT_ALL) slot = s - slot_base;
-            else if (p.out_mode == CARD_OUT_SELECT) slot = p.state_slot[s];
-            else return;
-            if (slot < 0 || !valid) return;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (c0 + k < C) p.out[slot * NC + row * C + c0 + k] = yv[k];
-        };
-        if (p.y_init) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) yv[k] = c0 + k < C ? p.y_init[rc * C + c0 + k] : 0.0f;
+            for (int k = 0; k < 4; ++k) yv[g][k] = c0 + k < C ? p.y_init[rc[g] * C + c0 + k] : 0.0f;
         } else {
             float z[4];
-            draw(0, z);
+            draw(g, 0, z);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) yv[k] = c0 + k < C ? z[k] + mu[k] : 0.0f;       // classification/diffusion_utils.py:123-124
-            store_state(0);
+            for (int k = 0; k < 4; ++k) yv[g][k] = c0 + k < C ? z[k] + mu[g][k] : 0.0f;       // classification/diffusion_utils.py:123-124
+            store_state(g, 0);
         }
-        *reinterpret_cast<f32x4*>(ysw) = f32x4{yv[0], yv[1], yv[2], yv[3]};
-        for (int i = tid; i < kGRow; i += kThreads) gsl[gcur * kGRow + i] = p.gtab[(long long)p.t_hi * kGRow + i];
-        __syncthreads();
+        *reinterpret_cast<f32x4*>(ysw[g]) = f32x4{yv[g][0], yv[g][1], yv[g][2], yv[g][3]};
+        for (int i = tid; i < kGRow; i += kThreads) gsl[g][i] = p.gtab[(long long)th[g] * kGRow + i];
+    }
+    __syncthreads();
 
-        auto publish = [&](const f32x16& a, int buf) {
+    auto publish = [&](int g, const f32x16& a, int buf) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<f32x4*>(exw + buf * kTileM * kExLd + 8 * q) = f32x4{a[4 * q + 0], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
-        };
-        auto hidden = [&](const float (&A)[64], int buf, int layer, const float* gl) -> f32x16 {
-            f32x16 acc;
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<f32x4*>(exw[g] + buf * kTileM * kExLd + 8 * q) = f32x4{a[4 * q + 0], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+    };
+    auto hidden = [&](int g, const float (&A)[64], int buf, int layer, const float* gl) -> f32x16 {
+        f32x16 acc;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 b = lds4(tb + layer * kF + 8 * q);
-                acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
-            }
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = lds4(tb + layer * kF + 8 * q);
+            acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
+        }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const f32x4 h = lds4(exr + buf * kTileM * kExLd + 32 * (i >> 2) + 8 * (i & 3));
+        for (int i = 0; i < 16; ++i) {
+            const f32x4 h = lds4(exr[g] + buf * kTileM * kExLd + 32 * (i >> 2) + 8 * (i & 3));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * i + e], h[e], acc, 0, 0, 0);
-            }
-            epilogue_bn(acc, gl + layer * kF + 32 * w, ts + layer * kF);
-            return acc;
-        };
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * i + e], h[e], acc, 0, 0, 0);
+        }
+        epilogue_bn(acc, gl + layer * kF + 32 * w, ts + layer * kF);
+        return acc;
+    };
 
-        for (int t = p.t_hi; t >= p.t_lo; --t) {
-            const bool more = t > p.t_lo;
-            f32x4 gn = {0.f, 0.f, 0.f, 0.f};
-            if (more && tid < kGRow / 4) gn = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(t - 1) * kGRow + tid * 4);
-            float z[4] = {0.f, 0.f, 0.f, 0.f};
-            if (t >= 1 && !p.eps_only) draw(T - t, z);
-            const float* const gl = gsl + gcur * kGRow + 4 * hh;
-
+    for (int it = 0; it < n_iter; ++it) {
+        bool on[G], more[G];
+        f32x4 gn[G];
+        float z[G][4];
+        const float* gl[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            on[g] = it < cnt[g];
+            more[g] = it + 1 < cnt[g];
+            gl[g] = gsl[g] + gcur[g] * kGRow + 4 * hh;
+            gn[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) z[g][k] = 0.0f;
+            if (!on[g]) continue;
+            const int t = th[g] - it;
+            if (more[g] && tid < kGRow / 4) gn[g] = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(t - 1) * kGRow + tid * 4);
+            if (t >= 1 && !p.eps_only) draw(g, T - t, z[g]);
             // layer 1 (model.py:82-87): c1 + W1[:, 0:C] . y_t, BN, softplus, Hadamard with x_feat
-            f32x16 acc = c1;
+            f32x16 acc = c1[g];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (q < p.nq1) {
-                    const f32x4 yb = lds4(ysr + 8 * q);
+                    const f32x4 yb = lds4(ysr[g] + 8 * q);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[4 * q + e], yb[e], acc, 0, 0, 0);
                 }
             }
-            epilogue_bn(acc, gl + 32 * w, ts);
+            epilogue_bn(acc, gl[g] + 32 * w, ts);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] *= xf[r];
-            publish(acc, 0);
-            __syncthreads();
-            acc = hidden(A2, 0, 1, gl);
-            publish(acc, 1);
-            __syncthreads();
-            acc = hidden(A3, 1, 2, gl);
-            if (more && tid < kGRow / 4) *reinterpret_cast<f32x4*>(gsl + (gcur ^ 1) * kGRow + tid * 4) = gn;
+            for (int r = 0; r < 16; ++r) acc[r] *= xf[g][r];
+            publish(g, acc, 0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (!on[g]) continue;
+            const f32x16 acc = hidden(g, A2, 0, 1, gl[g]);
+            publish(g, acc, 1);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (!on[g]) continue;
+            const f32x16 acc = hidden(g, A3, 1, 2, gl[g]);
+            if (more[g] && tid < kGRow / 4) *reinterpret_cast<f32x4*>(gsl[g] + (gcur[g] ^ 1) * kGRow + tid * 4) = gn[g];
             // lin4 (model.py:94): this wave's K = 32 slice of the 32-class x 32-chain tile
             f32x16 part;
 #pragma unroll
@@ -260,23 +331,27 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
             for (int r = 0; r < 16; ++r) part = __builtin_amdgcn_mfma_f32_32x32x2f32(A4[r], acc[r], part, 0, 0, 0);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<f32x4*>(red + (w * kTileM + m) * kYLd + 8 * q + 4 * hh) =
+                *reinterpret_cast<f32x4*>(red[g] + (w * kTileM + m) * kYLd + 8 * q + 4 * hh) =
                     f32x4{part[4 * q + 0], part[4 * q + 1], part[4 * q + 2], part[4 * q + 3]};
-            __syncthreads();
-            f32x4 eps = lds4(red + m * kYLd + c0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (!on[g]) continue;
+            const int t = th[g] - it;
+            f32x4 eps = lds4(red[g] + m * kYLd + c0);
 #pragma unroll
             for (int ww = 1; ww < kWaves; ++ww) {
-                const f32x4 v = lds4(red + (ww * kTileM + m) * kYLd + c0);
+                const f32x4 v = lds4(red[g] + (ww * kTileM + m) * kYLd + c0);
                 eps += v;
             }
             eps += b4v;
-            gcur ^= more ? 1 : 0;
-
+            gcur[g] ^= more[g] ? 1 : 0;
             if (p.eps_only) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (valid && c0 + k < C) p.out[row * C + c0 + k] = eps[k];
-                break;
+                    if (valid[g] && c0 + k < C) p.out[row[g] * C + c0 + k] = eps[k];
+                continue;
             }
             // posterior update per (chain, class), classification/diffusion_utils.py:80-86 (t >= 1) / :98-100 (t == 0)
             const float* c = p.coef + (long long)t * CARD_COEF_COLS;
@@ -284,21 +359,28 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
             const float g0 = c[CARD_COEF_G0], g1 = c[CARD_COEF_G1], g2 = c[CARD_COEF_G2], sg = c[CARD_COEF_SIGMA];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float y0r = ci * ((yv[k] - co * mu[k]) - eps[k] * cs);
+                const float y0r = ci * ((yv[g][k] - co * mu[g][k]) - eps[k] * cs);
                 float v = y0r;
-                if (t >= 1) v = ((g0 * y0r + g1 * yv[k]) + g2 * mu[k]) + sg * z[k];
-                yv[k] = c0 + k < C ? v : 0.0f;
+                if (t >= 1) v = ((g0 * y0r + g1 * yv[g][k]) + g2 * mu[g][k]) + sg * z[g][k];
+                yv[g][k] = c0 + k < C ? v : 0.0f;
             }
-            store_state(T - t);
-            *reinterpret_cast<f32x4*>(ysw) = f32x4{yv[0], yv[1], yv[2], yv[3]};
-            __syncthreads();
-        }
-        if (p.out_mode == CARD_OUT_LAST && !p.eps_only && valid) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (c0 + k < C) p.out[row * C + c0 + k] = yv[k];
+            store_state(g, T - t);
+            *reinterpret_cast<f32x4*>(ysw[g]) = f32x4{yv[g][0], yv[g][1], yv[g][2], yv[g][3]};
         }
         __syncthreads();
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (!valid[g] || p.eps_only) continue;
+        if (!last_seg[g]) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (c0 + k < C) p.ybuf[(row[g] - p.n_begin) * C + c0 + k] = yv[g][k];
+        } else if (p.out_mode == CARD_OUT_LAST) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (c0 + k < C) p.out[row[g] * C + c0 + k] = yv[g][k];
+        }
     }
 }
 
@@ -365,11 +447,11 @@ int clscoop_create(card_sampler* s, const card_model_desc* d, hipStream_t stream
     HIP_TRY(hipMalloc(&s->W4, (size_t)kWaves * 4 * 256 * sizeof(float)));
     HIP_TRY(hipMalloc(&s->bias, (size_t)kTab * sizeof(float)));
     HIP_TRY(hipMalloc(&s->gtab, (size_t)d->n_embed * kGRow * sizeof(float)));
-    s->lds_bytes = (size_t)kLdsFloats * sizeof(float);
-    HIP_TRY(hipFuncSetAttribute((const void*)card_sample_cls_coop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
-    int nb = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)card_sample_cls_coop_kernel, kThreads, s->lds_bytes));
-    s->coop_blocks = nb < 1 ? 1 : (nb > 2 ? 2 : nb);
+    HIP_TRY(hipMalloc(&s->ws, (size_t)kChunkTiles * kTileM * C * sizeof(float)));      // chain states between time slices
+    s->lds_bytes = (size_t)lds_floats(kGmax) * sizeof(float);
+    HIP_TRY(hipFuncSetAttribute((const void*)card_sample_cls_coop_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats(1) * sizeof(float))));
+    HIP_TRY(hipFuncSetAttribute((const void*)card_sample_cls_coop_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats(2) * sizeof(float))));
+    s->coop_blocks = 1;
     cls_pack_hidden_kernel<<<kF * kF / 256, 256, 0, stream>>>(d->W[1], s->wpk);
     cls_pack_hidden_kernel<<<kF * kF / 256, 256, 0, stream>>>(d->W[2], s->wpk + kF * kF);
     cls_pack_first_kernel<<<8, 256, 0, stream>>>(d->W[0], C, d_in, nq1, s->w1s);
@@ -383,7 +465,7 @@ int clscoop_create(card_sampler* s, const card_model_desc* d, hipStream_t stream
 }
 
 void clscoop_destroy(card_sampler* s) {
-    float* bufs[] = {s->wpk, s->w1s, s->W4, s->bias, s->gtab};
+    float* bufs[] = {s->wpk, s->w1s, s->W4, s->bias, s->gtab, s->ws};
     for (float* b : bufs)
         if (b) (void)hipFree(b);
 }
@@ -396,10 +478,59 @@ int clscoop_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     p.state_slot = r.state_slot; p.N = r.N; p.seed = r.seed; p.elem_offset = r.elem_offset;
     p.T = r.T; p.t_hi = r.t_hi; p.t_lo = r.t_lo; p.C = s->y_dim; p.nq1 = s->nqs; p.guidance = s->cat_y_pred;
     p.out_mode = r.out_mode; p.eps_only = r.eps_only; p.n_z = r.n_z;
-    const long long tiles = (r.N + kTileM - 1) / kTileM;
-    const long long cap = (long long)s->num_cu * s->coop_blocks;
-    const long long grid = tiles < cap ? tiles : cap;
-    card_sample_cls_coop_kernel<<<dim3((unsigned)grid), dim3(kThreads), s->lds_bytes, stream>>>(p);
-    HIP_TRY(hipGetLastError());
+    // hand-over buffer of the time slices: the sampler's own, or the library's static array (card_sampler_run_static)
+    p.ybuf = s->ws;
+    long long chunk_tiles = kChunkTiles;
+    if (r.lib_scratch) {
+        p.ybuf = static_cast<float*>(r.workspace);
+        const long long fit = (long long)(r.workspace_bytes / ((size_t)kTileM * s->y_dim * sizeof(float)));
+        chunk_tiles = fit < chunk_tiles ? fit : chunk_tiles;
+    }
+    const char* ev = getenv("CARD_AMD_CLSCOOP_G");              // A/B: tile positions per workgroup (1 or 2)
+    const int G = (ev && ev[0] == '1') ? 1 : kGmax;
+    const char* sv = getenv("CARD_AMD_CLSCOOP_SLICE");          // A/B: 0 = no time slicing (rounds of whole loops)
+    const bool slicing = !(sv && sv[0] == '0');
+    const long long P = (long long)s->num_cu * G;               // slots one launch runs
+    const int n_steps = r.t_hi - r.t_lo + 1;
+    auto launch = [&](int g_eff, long long grid) -> int {
+        p.g_eff = g_eff;
+        if (g_eff == 1) card_sample_cls_coop_kernel<1><<<dim3((unsigned)grid), dim3(kThreads), lds_floats(1) * sizeof(float), stream>>>(p);
+        else card_sample_cls_coop_kernel<2><<<dim3((unsigned)grid), dim3(kThreads), lds_floats(2) * sizeof(float), stream>>>(p);
+        HIP_TRY(hipGetLastError());
+        return CARD_OK;
+    };
+    const long long tiles_total = (r.N + kTileM - 1) / kTileM;
+    for (long long t0 = 0; t0 < tiles_total; t0 += chunk_tiles) {
+        const long long nt = tiles_total - t0 < chunk_tiles ? tiles_total - t0 : chunk_tiles;
+        p.n_begin = t0 * kTileM;
+        p.n_end = (t0 + nt) * kTileM < r.N ? (t0 + nt) * kTileM : r.N;
+        if (nt <= s->num_cu) {                                   // one tile per workgroup, one launch
+            p.n_seg = 1; p.q0 = 0; p.q1 = nt;
+            if (int rc = launch(1, nt)) return rc;
+            continue;
+        }
+        // segments: as many as make the last, partly filled slice cheap, at >= 32 timesteps each; one segment (whole
+        // loops, workgroups walking ceil(nt / P) rounds... here: slices of whole loops) when slicing is off or useless
+        int n_seg = 1;
+        if (slicing && !r.eps_only && nt > P && n_steps >= 64 && chunk_tiles >= P) {
+            double best = 1e300;
+            for (int ns = 1; ns <= 16 && n_steps / ns >= 32; ++ns) {
+                const long long slices = (nt * ns + P - 1) / P;
+                const double cost = (double)slices * (double)((n_steps + ns - 1) / ns) + 4.0 * (double)slices;   // + launch overhead in timestep units
+                if (cost < best) { best = cost; n_seg = ns; }
+            }
+        }
+        p.n_seg = n_seg;
+        const long long slots = nt * n_seg;
+        // a slice must not hold two segments of one tile: slices of at most nt slots (P <= nt whenever n_seg > 1)
+        const long long per = n_seg > 1 ? P : (nt < P ? nt : P);
+        for (long long q0 = 0; q0 < slots; q0 += per) {
+            p.q0 = q0;
+            p.q1 = q0 + per < slots ? q0 + per : slots;
+            const long long n = p.q1 - p.q0;
+            const int g_eff = n > s->num_cu ? G : 1;
+            if (int rc = launch(g_eff, (n + g_eff - 1) / g_eff)) return rc;
+        }
+    }
     return CARD_OK;
 }

@@ -20,7 +20,7 @@ from .sampler import (coef_on_device, make_coef_table, sampler_for, x_features, 
 # every public name of regression/diffusion_utils.py and classification/diffusion_utils.py (the runners star-import the
 # module: regression/card_regression.py:16 uses kld at :685), plus this package's extras
 __all__ = ["make_beta_schedule", "extract", "q_sample", "p_sample", "p_sample_t_1to0", "p_sample_loop", "kld",
-           "y_0_reparam", "p_sample_loop_with_eval", "p_sample_loop_with_y", "p_sample_loop_from_x"]
+           "y_0_reparam", "p_sample_loop_with_eval", "p_sample_loop_with_y", "p_sample_loop_from_x", "p_sample_loop_repeated"]
 
 
 def make_beta_schedule(schedule="linear", num_timesteps=1000, start=1e-5, end=1e-2):
@@ -315,6 +315,18 @@ def p_sample_loop_from_x(model, f_phi, x, n_steps, alphas, one_minus_alphas_bar_
         return s.run(x, None, mu, coef, T, out_mode=_lib.OUT_LAST, **kw), y0hat
     seq = s.run(x, None, mu, coef, T, out_mode=_lib.OUT_ALL, **kw)
     return list(seq.unbind(0)), y0hat
+
+
+def p_sample_loop_repeated(model, x, y_0_hat, y_T_mean, n_steps, alphas, one_minus_alphas_bar_sqrt, n_repeats, *,
+                           noise=None, seed=None, elem_offset=0):
+    """classification/imagenet/main.py:555-566 (save_prediction): the reference calls
+    `p_sample_loop(..., only_last_sample=True)` n_repeats = 1000 times on the same batch and stacks the results to
+    (B, n_repeats, n_classes).  Here the repeats are the in-kernel row tiling: ONE sampling call over B * n_repeats chains
+    (x, y_0_hat, y_T_mean stay (B, .)), returned in the reference's (B, n_repeats, n_classes) layout.
+    noise: optional (n_steps, B * n_repeats, n_classes), chain order (image, repeat)."""
+    y0 = p_sample_loop(model, x, y_0_hat, y_T_mean, n_steps, alphas, one_minus_alphas_bar_sqrt, True, noise=noise,
+                       seed=seed, elem_offset=elem_offset, n_z=int(n_repeats))
+    return y0.view(int(y_0_hat.shape[0]), int(n_repeats), -1)
 
 
 def kld(y1, y2, grid=(-20, 20), num_grid=400):

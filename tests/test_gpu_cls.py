@@ -202,6 +202,17 @@ def test_imagenet_linear_head_matches_reference():
     s = card_amd.sampler_for(m)
     eps = s.eps_theta(cuda(g["x_feat"]), cuda(g["traj"][T - 3]), cuda(g["y0hat"]), 3).cpu()
     assert norm_rel_err(eps, g["raw"]["eps.t3"]) <= TOL
+    # save_prediction's repeated sampling (imagenet/main.py:555-566) as one call: (B, n_repeats, C), repeat r of image b
+    # equals a separate p_sample_loop call fed the noise of chain (b, r)
+    B, R = g["y0hat"].shape[0], 5
+    nz = torch.randn(T, B * R, C, generator=torch.Generator().manual_seed(2))
+    rep = card_amd.p_sample_loop_repeated(*args, R, noise=cuda(nz))
+    assert rep.shape == (B, R, C)
+    for r in range(R):
+        one = card_amd.p_sample_loop(*args, True, noise=cuda(nz[:, r::R].contiguous()))
+        assert torch.equal(rep[:, r], one), r
+    again = card_amd.p_sample_loop_repeated(*args, R, seed=3)
+    assert torch.equal(again, card_amd.p_sample_loop_repeated(*args, R, seed=3)) and again.shape == (B, R, C)
 
 
 @pytest.mark.parametrize("num_ts", [None, [1, 8, 9, 30, 51], [51], [17]])
@@ -303,3 +314,49 @@ def test_bn_model_in_train_mode_is_refused():
     card_amd.p_sample_loop(m, *args, True, seed=1)              # cached while in eval mode ...
     with pytest.raises(_lib.CardError, match="eval mode"):      # ... and still refused once switched to train mode
         card_amd.p_sample_loop(m.train(), *args, True, seed=1)
+
+
+@pytest.mark.parametrize("rows,n_z,C", [(250, 100, 10), (173, 97, 3), (40, 100, 10)])
+def test_f128_time_sliced_two_tile_form_is_bit_identical(rows, n_z, C, monkeypatch, f128_kernel):
+    """card_clscoop.hip: workgroups advancing two tiles at once and the round-robin time slicing (782 tiles = the MNIST
+    test minibatch of 250 images x 100 z, classification/configs/mnist.yml) against the plain form (one tile per
+    workgroup, whole loops): same bits in every output mode, also through the entry point that allocates nothing."""
+    if f128_kernel != "coop":
+        pytest.skip("cooperative kernel only")
+    T = 130
+    sd = cls_state_dict(128, C, T, 5)
+    gen = torch.Generator().manual_seed(6)
+    xf = cuda(torch.randn(rows, 128, generator=gen))
+    y0 = cuda(torch.softmax(torch.randn(rows, C, generator=gen) * 2, 1))
+    alphas, _, omabs = orc.make_schedule("linear", T, 1e-4, 0.1)
+    coef = cuda(make_coef_table(alphas, omabs))
+    outs = {}
+    for name, g, sl in (("sliced2", "2", "1"), ("plain1", "1", "0"), ("sliced1", "1", "1"), ("plain2", "2", "0")):
+        monkeypatch.setenv("CARD_AMD_CLSCOOP_G", g)
+        monkeypatch.setenv("CARD_AMD_CLSCOOP_SLICE", sl)
+        s = Sampler.from_cls_state_dict(sd, device=DEV)
+        last = s.run(xf, y0, y0, coef, T, seed=12, elem_offset=3, n_z=n_z)
+        sel = s.run(xf, y0, y0, coef, T, seed=12, elem_offset=3, n_z=n_z, out_mode=_lib.OUT_SELECT, states=[0, 1, 64, 65, T])
+        seg = s.run(xf, y0, y0, coef, T, seed=12, elem_offset=3, n_z=n_z, t_hi=100, t_lo=7, y_init=sel[2])
+        outs[name] = (last, sel, seg)
+        if name == "sliced2":
+            assert torch.equal(s.run(xf, y0, y0, coef, T, seed=12, elem_offset=3, n_z=n_z, static_scratch=True), last)
+    for name in ("plain1", "sliced1", "plain2"):
+        for a, b in zip(outs["sliced2"], outs[name]):
+            assert torch.equal(a, b) and torch.isfinite(a).all(), name
+    assert torch.equal(outs["sliced2"][0], outs["sliced2"][1][-1])
+    # and against the oracle under injected noise on the first and the last input row's chains
+    w = orc.ClsWeights.from_state_dict(sd, guidance=True)
+    monkeypatch.setenv("CARD_AMD_CLSCOOP_G", "2")
+    monkeypatch.setenv("CARD_AMD_CLSCOOP_SLICE", "1")
+    s = Sampler.from_cls_state_dict(sd, device=DEV)
+    N = rows * n_z
+    noise = torch.randn(T, N, C, generator=gen)
+    got = s.run(xf, y0, y0, coef, T, noise=cuda(noise), n_z=n_z).cpu()
+    for r in (0, rows - 1):
+        sl_ = slice(r * n_z, r * n_z + 16)
+        tile = lambda t: t[r:r + 1].cpu().repeat(16, 1)
+        want = orc.p_sample_loop(w, tile(xf), tile(y0), tile(y0), T, alphas, omabs, noise[:, sl_], only_last_sample=True)
+        err = norm_rel_err(got[sl_], want)
+        print(f"sliced cls kernel rows={rows} n_z={n_z} C={C}, row {r}: norm-rel err vs oracle {err:.2e}")
+        assert err <= TOL
