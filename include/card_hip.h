@@ -189,7 +189,8 @@ CARD_API int card_sampler_run(const card_sampler* s, const card_run_args* args, 
 /* card_sampler_run for callers that cannot allocate device memory or pass a workspace: code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE.  Same arguments and results as
  * card_sampler_run (args->workspace / workspace_bytes are ignored); every scratch buffer -- the per-wave layer-1 slots of
- * the persistent scratch-slot kernel, the activations of the GEMM back end -- lives in ONE array of
+ * the persistent scratch-slot kernel, the chain states handed between the launches of the time-sliced cooperative kernels,
+ * the activations of the GEMM back end -- lives in ONE array of
  * CARD_STATIC_SCRATCH_BYTES that the library holds on each GPU it runs on until the process ends.  The call allocates
  * nothing (no hipMalloc / hipFree, no allocating library routine).  Limits: on the GEMM back end the batch is walked in
  * chunks of as many chains as the array holds (12 483 at hidden 256, 1 004 at hidden 4096); if not even one input row's
