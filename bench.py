@@ -191,6 +191,22 @@ def main():
             chunk = cu * WAVES_PER_CU * TILES_PER_WAVE_PER_LAUNCH * TILE_M if H == 128 else cu * 8 * 128   # guided_run / stream_run
             launches = math.ceil(N / chunk) * a.steps
             kernel = "card_sample_guided_kernel" if H == 128 else "card_sample_stream_kernel"
+            if H == 128 and N <= 7 * cu * 32:
+                # guided_run(): small batches run on the cooperative kernels, between one and two tiles per CU time-sliced
+                def slices(tiles, rho):
+                    if not cu < tiles < 2 * cu or T < 64:
+                        return 1
+                    n_single = 2 * cu - tiles
+                    K = math.ceil(tiles / n_single)
+                    S = int(T / (K - 1 + rho) + 0.5)
+                    return K if (K <= 8 and S >= 8 and T - (K - 1) * S >= S) else 1
+                t16, t32 = math.ceil(N / 16), math.ceil(N / 32)
+                if t16 <= 2 * cu - cu // 8:
+                    kernel, launches = "card_sample_coop16_kernel", slices(t16, 1.65) * a.steps
+                elif cu < t32 < 2 * cu:
+                    kernel, launches = "card_sample_coop2_kernel", slices(t32, 1.717) * a.steps
+                else:
+                    kernel, launches = "card_sample_coop_kernel", a.steps
         elif cls_coop:
             # clscoop_run(): one launch up to num_cu tiles, else round-robin time slices of num_cu x 2 (tile, segment) slots
             cu = torch.cuda.get_device_properties(dev).multi_processor_count

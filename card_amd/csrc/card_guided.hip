@@ -73,6 +73,8 @@ struct GuidedParams {
     // time-sliced cooperative launches (card_sample_coop2_kernel): this launch is slice sl_k of sl_K
     int sl_k, sl_K, sl_nsingle, sl_S, sl_L;
     float* ybuf;          // (N) chain states handed from one slice to the next
+    const float* wpk16;   // card_sample_coop16_kernel: W2 | W3 in 16x16x4 fragment order (x ln2)
+    const float* w1s16;   // ... and the static columns of W1: [(w, mb), q, e][64]
 };
 
 
@@ -805,6 +807,267 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop2_kernel(con
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fewer than two 32-chain tiles per CU: 16-chain tiles (card_sample_coop16_kernel).
+// A tile-timestep of the kernels above is a dependent chain of 130 v_mfma_f32_32x32x2_f32 per wave whatever the batch,
+// so 5 100 chains (BASELINE configs[0], 160 tiles) leave 96 CUs idle and take as long as 8 192.  This kernel is
+// card_sample_coop2_kernel (two cooperative halves per workgroup, time-sliced between one and two tiles per CU) on
+// 16-chain tiles with v_mfma_f32_16x16x4_f32 (D[feature 4g + r][chain n] on lane 16g + n): half the MFMA time per
+// tile-timestep and twice as many tiles to spread.
+// It is BIT-IDENTICAL to the 32-chain kernels: on gfx950 both fp32 MFMA shapes are plain sequential fp32 FMA chains over
+// k in index order (tools/ubench/mfma_order.hip: 0 mismatches against a host fmaf chain), so it is enough to feed the
+// input features of every layer in the same order.  The 32-chain kernels consume (f, f + 4) per MFMA for
+// f = 8i + e, i = 0..15, e = 0..3; here MFMA s (k = lane group g) takes feature 8(s>>1) + 2(s&1) + (g>>1) + 4(g&1).
+// The activation exchange tile is stored in that order (slot 16a + 4g + j for MFMA s = 4a + j), so a lane still fetches
+// the B operands of four MFMAs with one ds_read_b128; lin4's partial sums follow the other kernels' association
+// (two 16-feature chains per wave handed between lane groups with __shfl_xor, then added).
+// ------------------------------------------------------------------------------------------------
+constexpr int kT16 = 16;
+constexpr int kHalf16LdsFloats = 2 * kT16 * kExLd + kCoopWaves * kT16 + 2 * kGammaRow;
+constexpr int kCoop16LdsFloats = 2 * kHalf16LdsFloats + kTabFloats;
+constexpr int kImg16Floats = 2 * kH * kH;                 // W2 | W3 in 16x16x4 fragment order
+
+// gamma multiply + softplus of this wave's 32 features x 16 chains (two 16-feature accumulator blocks), staged
+__device__ __forceinline__ void epilogue16(f32x4 (&acc)[2], const float* gl) {
+    float xs[8], e[8];
+    __builtin_amdgcn_s_setprio(kPrioValu);
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const f32x4 g = lds4(gl + 16 * mb);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xs[4 * mb + k] = acc[mb][k] * g[k];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) e[r] = __builtin_amdgcn_exp2f(xs[r]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) e[r] = 1.0f + e[r];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) e[r] = __builtin_amdgcn_logf(e[r]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r >> 2][r & 3] = __builtin_amdgcn_fmed3f(e[r], xs[r], kSpThresh);
+    __builtin_amdgcn_s_setprio(kPrioMfma);
+}
+
+__global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(const RunParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave >> 2, w = wave & 3;
+    const int htid = tid & (kCoopThreads - 1);
+    float* const ex = lds + half * kHalf16LdsFloats;               // 2 exchange tiles [16][132], permuted feature order
+    float* const red = ex + 2 * kT16 * kExLd;                      // [4][16] lin4 partial sums
+    float* const gsl = red + kCoopWaves * kT16;                    // 2 gamma rows
+    float* const tab = lds + 2 * kHalf16LdsFloats;
+    const int n = lane & 15, g = lane >> 4;
+    for (int i = tid; i < kTabFloats; i += kCoop2Threads) tab[i] = p.wpk[kOffB + i];
+
+    // ---- which tile this half advances in this slice (same scheme as card_sample_coop2_kernel)
+    const long long n_tiles = (p.n_end - p.n_begin + kT16 - 1) / kT16;
+    const int k = p.sl_k, nsg = p.sl_nsingle;
+    const long long first_single = (long long)k * nsg;
+    long long n_s = n_tiles - first_single;
+    n_s = n_s < 0 ? 0 : (n_s > nsg ? nsg : n_s);                   // nsg = 0: every tile shares a CU
+    long long tile = -1;
+    int quota = 0;
+    if ((long long)blockIdx.x < n_s) {
+        if (half == 0) { tile = first_single + blockIdx.x; quota = p.sl_L; }
+    } else {
+        const long long j = 2 * ((long long)blockIdx.x - n_s) + half;
+        if (j < n_tiles - n_s) { tile = j < first_single ? j : j + n_s; quota = p.sl_S; }
+    }
+    const int n_iter = (long long)blockIdx.x < n_s ? p.sl_L : p.sl_S;
+    const bool active = tile >= 0;
+    const int before = k * p.sl_S + ((active && nsg > 0 && tile / nsg < k) ? p.sl_L - p.sl_S : 0);
+    const int th = p.t_hi - before;
+    const bool first_seg = before == 0, last_seg = th - quota + 1 <= p.t_lo;
+
+    // this wave's A fragments: A[mb][s] = W[32w + 16mb + (lane & 15)][feature(s, lane >> 4)]
+    float A2[64], A3[64];
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {                   // i = 8 mb + a: MFMAs s = 4a .. 4a + 3 of block mb
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p.wpk16 + ((w * 16 + i) * 64 + lane) * 4);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p.wpk16 + kH * kH + ((w * 16 + i) * 64 + lane) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { A2[4 * i + e] = a[e]; A3[4 * i + e] = b[e]; }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) { A2[i] = 0.0f; A3[i] = 0.0f; }
+    }
+    __syncthreads();
+    const float* const tb = tab + 32 * w + 4 * g;                                  // bias: + layer * kH + 16 mb
+    const float* const w4l = tab + (kOffW4 - kOffB) + 32 * w + 4 * g;              // + 16 mb
+    const float b4 = tab[kOffB4 - kOffB];
+    float a10[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) a10[mb] = g == 0 ? tab[(kOffW1 - kOffB) + 32 * w + 16 * mb + n] : 0.0f;
+    // publish: features 32w + 16mb + 4g + r go to slots 16(2w + mb) + 4(g&1) + 2(g>>1) + {0, 8, 1, 9}[r]
+    float* const exw = ex + n * kExLd + 32 * w + 4 * (g & 1) + 2 * (g >> 1);
+    const float* const exr = ex + n * kExLd + 4 * g;                               // + 16a: B operands of MFMAs 4a .. 4a+3
+    const int T = p.T;
+    const int draw0 = p.y_init ? (T - p.t_hi) : 0;
+    const int slot_base = draw0;
+
+    const long long row = p.n_begin + (active ? tile : 0) * kT16 + n;
+    const bool valid = active && row < p.n_end;
+    const long long rc = row < p.n_end ? row : p.n_end - 1;
+    const long long rr = p.n_z > 1 ? rc / p.n_z : rc;
+    const float mu = p.ytmean[rr];
+    const float y0h = p.y0hat[rr];
+    const unsigned long long elem = p.elem_offset + (unsigned long long)rc;
+    auto static_feature = [&](int kk) -> float {
+        if (p.cat_y_pred && kk == 1) return y0h;
+        const int xi = kk - 1 - (p.cat_y_pred ? 1 : 0);
+        return (p.cat_x && xi < p.x_dim) ? p.x[rr * p.x_dim + xi] : 0.0f;
+    };
+    // hoisted layer 1: c1 = b1 + W1[:, 1:] . (y_0_hat, x); MFMA s takes static feature 1 + 4s + g (the 32-chain
+    // kernels' order 1, 2, 3, ...)
+    f32x4 c1[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) c1[mb] = lds4(tb + 16 * mb);
+    if (active) {
+        for (int q = 0; q < p.nqs; ++q) {                  // 8 static features per q: two MFMAs per block
+            float bq[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) bq[e] = static_feature(1 + 8 * q + 4 * e + g);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float a = p.w1s16[((long long)((w * 2 + mb) * p.nqs + q) * 2 + e) * 64 + lane];
+                    c1[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq[e], c1[mb], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float zc[4];
+    uint32_t zblock = 0xFFFFFFFFu;
+    auto draw = [&](int d) -> float {
+        if (p.noise) return p.noise[(long long)(d - draw0) * p.N + rc];
+        const uint32_t blk = (uint32_t)d >> 2;
+        if (blk != zblock) {
+            philox_normal4(p.seed, elem, blk, zc);
+            zblock = blk;
+        }
+        return pick4(zc, d & 3);
+    };
+    auto store_state = [&](int s, float v) {
+        long long slot;
+        if (p.out_mode == CARD_OUT_ALL) slot = s - slot_base;
+        else if (p.out_mode == CARD_OUT_SELECT) slot = p.state_slot[s];
+        else return;
+        if (slot >= 0 && valid && g == 0 && w == 0) p.out[slot * p.N + row] = v;
+    };
+    float y = 0.0f;
+    if (active) {
+        if (!first_seg) {
+            y = p.ybuf[rc];
+        } else if (p.y_init) {
+            y = p.y_init[rc];
+        } else {
+            y = draw(0) + mu;                                 // diffusion_utils.py:109-110
+            store_state(0, y);
+        }
+        for (int i = htid; i < kGammaRow; i += kCoopThreads) gsl[i] = p.gtab[(long long)th * kGammaRow + i];
+    }
+    __syncthreads();
+    int gcur = 0;
+
+    auto publish = [&](const f32x4 (&a)[2], int buf) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            float* d = exw + buf * kT16 * kExLd + 16 * mb;
+            *reinterpret_cast<float2*>(d) = float2{a[mb][0], a[mb][2]};
+            *reinterpret_cast<float2*>(d + 8) = float2{a[mb][1], a[mb][3]};
+        }
+    };
+    auto hidden = [&](const float (&A)[64], int buf, int layer, const float* gl, f32x4 (&acc)[2]) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) acc[mb] = lds4(tb + layer * kH + 16 * mb);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const f32x4 h = lds4(exr + buf * kT16 * kExLd + 16 * a);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[4 * a + e], h[e], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[32 + 4 * a + e], h[e], acc[1], 0, 0, 0);
+            }
+        }
+        epilogue16(acc, gl + layer * kH + 32 * w);
+    };
+
+    for (int it = 0; it < n_iter; ++it) {
+        const bool on = active && it < quota;
+        const int t = th - it;
+        const bool more = on && it + 1 < quota;
+        f32x4 gn = {0.f, 0.f, 0.f, 0.f};
+        float z = 0.0f;
+        f32x4 acc[2];
+        const float* const gl = gsl + gcur * kGammaRow + 4 * g;
+        if (on) {
+            if (more && htid < kGammaRow / 4) gn = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(t - 1) * kGammaRow + htid * 4);
+            z = t >= 1 && !p.eps_only ? draw(T - t) : 0.0f;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a10[mb], g == 0 ? y : 0.0f, c1[mb], 0, 0, 0);
+            epilogue16(acc, gl + 32 * w);
+            publish(acc, 0);
+        }
+        __syncthreads();
+        if (on) {
+            hidden(A2, 0, 1, gl, acc);
+            publish(acc, 1);
+        }
+        __syncthreads();
+        if (on) {
+            hidden(A3, 1, 2, gl, acc);
+            if (more && htid < kGammaRow / 4) *reinterpret_cast<f32x4*>(gsl + (gcur ^ 1) * kGammaRow + htid * 4) = gn;
+            // lin4 in the 32-chain kernels' association: the chain over features 8q + e (q, e ascending) lives on lane
+            // groups 0 -> 2 -> 0 -> 2, the one over 8q + 4 + e on 1 -> 3 -> 1 -> 3; each finished chain is added to the other
+            float part = 0.0f;
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph) {
+                if (ph > 0) part = __shfl_xor(part, 32, 64);
+                const f32x4 wv = lds4(w4l + 16 * (ph >> 1));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float nx = fmaf(acc[ph >> 1][e], wv[e], part);
+                    part = ((g >> 1) == (ph & 1)) ? nx : part;       // only the lane groups whose turn it is advance
+                }
+            }
+            part += __shfl_xor(part, 16, 64);
+            if (g == 2) red[w * kT16 + n] = part;
+        }
+        __syncthreads();
+        if (on) {
+            const float eps = (((red[n] + red[kT16 + n]) + red[2 * kT16 + n]) + red[3 * kT16 + n]) + b4;
+            gcur ^= more ? 1 : 0;
+            if (p.eps_only) {
+                if (valid && g == 0 && w == 0) p.out[row] = eps;
+            } else {
+                const float* c = p.coef + (long long)t * CARD_COEF_COLS;
+                const float y0r = c[CARD_COEF_INV_SQRT_AB] * ((y - c[CARD_COEF_ONE_M_SQRT_AB] * mu) - eps * c[CARD_COEF_SOMAB]);
+                if (t >= 1) {
+                    const float yh = (c[CARD_COEF_G0] * y0r + c[CARD_COEF_G1] * y) + c[CARD_COEF_G2] * mu;
+                    y = yh + c[CARD_COEF_SIGMA] * z;
+                } else {
+                    y = y0r;
+                }
+                store_state(T - t, y);
+            }
+        }
+    }
+    if (valid && g == 0 && w == 0 && !p.eps_only) {
+        if (!last_seg) p.ybuf[row] = y;
+        else if (p.out_mode == CARD_OUT_LAST) p.out[row] = y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // create-time packing kernels
 // ------------------------------------------------------------------------------------------------
 // A-operand fragment order of a 128x128 layer: element e of lane l in block (j, jj, q) is
@@ -835,6 +1098,26 @@ __global__ void pack_static_kernel(const float* __restrict__ W1, int d_in, int n
     const int e = idx & 3, l = (idx >> 2) & 63, rest = idx >> 8, q = rest % nqs, j = rest / nqs;
     const int n = 32 * j + (l & 31), k = 1 + 8 * q + 2 * e + (l >> 5);
     out[idx] = k < d_in ? W1[n * d_in + k] : 0.0f;
+}
+
+// 16x16x4 fragment order (card_sample_coop16_kernel): element e of lane l in block (w, i = 8 mb + a) is
+// W[32w + 16mb + (l&15)][feature(s = 4a + e, g = l>>4)], feature(s, g) = 8(s>>1) + 2(s&1) + (g>>1) + 4(g&1)
+__global__ void pack_hidden16_kernel(const float* __restrict__ W, float scale, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= kH * kH) return;
+    const int e = idx & 3, l = (idx >> 2) & 63, i = (idx >> 8) & 15, w = idx >> 12;
+    const int mb = i >> 3, a = i & 7, s = 4 * a + e, g = l >> 4;
+    const int nrow = 32 * w + 16 * mb + (l & 15), k = 8 * (s >> 1) + 2 * (s & 1) + (g >> 1) + 4 * (g & 1);
+    out[idx] = W[nrow * kH + k] * scale;
+}
+
+// static columns of W1 for the 16-chain kernel: [(w, mb), q, e][lane] = W1[32w + 16mb + (l&15)][1 + 8q + 4e + (l>>4)]
+__global__ void pack_static16_kernel(const float* __restrict__ W1, int d_in, int nqs, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 8 * nqs * 2 * 64) return;
+    const int l = idx & 63, e = (idx >> 6) & 1, rest = idx >> 7, q = rest % nqs, wm = rest / nqs;
+    const int nrow = 16 * wm + (l & 15), k = 1 + 8 * q + 4 * e + (l >> 4);
+    out[idx] = k < d_in ? W1[nrow * d_in + k] : 0.0f;
 }
 
 __global__ void pack_col0_kernel(const float* __restrict__ W1, int d_in, float* __restrict__ out) {
@@ -909,6 +1192,13 @@ int guided_create(card_sampler* s, const card_model_desc* d, hipStream_t stream)
         s->coop_force = (cv && cv[0] == '2') ? 1 : 0;     // CARD_AMD_COOP=2: cooperative kernel for every batch size (A/B)
         HIP_TRY(hipFuncSetAttribute((const void*)card_sample_coop2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(kCoop2LdsFloats * sizeof(float))));
+        HIP_TRY(hipFuncSetAttribute((const void*)card_sample_coop16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(kCoop16LdsFloats * sizeof(float))));
+        HIP_TRY(hipMalloc(&s->wpk16, (size_t)kImg16Floats * sizeof(float)));
+        if (nqs > 0) HIP_TRY(hipMalloc(&s->w1s16, (size_t)8 * nqs * 2 * 64 * sizeof(float)));
+        pack_hidden16_kernel<<<kH * kH / 256, 256, 0, stream>>>(d->W[1], kLn2, s->wpk16);
+        pack_hidden16_kernel<<<kH * kH / 256, 256, 0, stream>>>(d->W[2], kLn2, s->wpk16 + kH * kH);
+        if (nqs > 0) pack_static16_kernel<<<(8 * nqs * 2 * 64 + 255) / 256, 256, 0, stream>>>(d->W[0], d_in, nqs, s->w1s16);
     }
     pack_hidden_kernel<<<kH * kH / 256, 256, 0, stream>>>(d->W[1], kLn2, s->wpk + kOffW2);
     pack_hidden_kernel<<<kH * kH / 256, 256, 0, stream>>>(d->W[2], kLn2, s->wpk + kOffW3);
@@ -930,6 +1220,8 @@ void guided_destroy(card_sampler* s) {
     if (s->gtab) (void)hipFree(s->gtab);
     if (s->w1s) (void)hipFree(s->w1s);
     if (s->ws) (void)hipFree(s->ws);
+    if (s->wpk16) (void)hipFree(s->wpk16);
+    if (s->w1s16) (void)hipFree(s->w1s16);
 }
 
 int guided_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
@@ -942,6 +1234,7 @@ int guided_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     p.x_dim = s->x_dim; p.cat_x = s->cat_x; p.cat_y_pred = s->cat_y_pred;
     p.out_mode = r.out_mode; p.eps_only = r.eps_only; p.n_z = r.n_z;
     p.w1s = s->w1s; p.ws = s->ws; p.nqs = s->nqs;
+    p.wpk16 = s->wpk16; p.w1s16 = s->w1s16;
     if (r.lib_scratch) {
         // card_sampler_run_static: the per-wave slots of the scratch-slot kernel come from the library's static array
         const unsigned long long need = (unsigned long long)s->num_cu * kWaves * kSlotFloats * sizeof(float);
@@ -960,6 +1253,39 @@ int guided_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     if (s->coop_blocks > 0 && (s->coop_force || tiles_total <= 7LL * s->num_cu)) {
         p.n_begin = 0;
         p.n_end = p.N;
+        // Up to two 16-chain tiles per CU (8 192 chains on 256 CUs; BASELINE configs[0] is 5 100): the 16-chain-tile kernel,
+        // one tile per CU up to num_cu tiles, the time-sliced single / paired scheme between num_cu and 2 x num_cu.
+        // CARD_AMD_COOP16=0: off (A/B; results are bit-identical either way).
+        const char* c16 = getenv("CARD_AMD_COOP16");
+        const long long tiles16 = (p.N + kT16 - 1) / kT16;
+        // (a CU sharing two 16-chain tiles takes 5.46 us per timestep, one 32-chain tile alone 5.3 us: above 15/8 tiles
+        // per CU the 32-chain form below is as fast)
+        if (s->coop_blocks == 2 && !(c16 && c16[0] == '0') && s->wpk16 && tiles16 <= 2LL * s->num_cu - s->num_cu / 8 && p.ws) {
+            const int n_steps16 = p.t_hi - p.t_lo + 1;
+            long long n_single = tiles16 <= s->num_cu ? tiles16 : 2LL * s->num_cu - tiles16;
+            int K = 1, S = n_steps16, L = n_steps16;
+            const bool fits16 = !r.lib_scratch || (unsigned long long)p.N * sizeof(float) <= r.workspace_bytes;
+            if (tiles16 > s->num_cu && n_single > 0 && !p.eps_only && n_steps16 >= 64 && fits16) {
+                double rho = 1.65;                                 // paired (5.46 us) / single (3.3 us) cost of a timestep, measured
+                if (const char* rv = getenv("CARD_AMD_COOP16_RHO")) rho = atof(rv) > 1.0 ? atof(rv) : rho;
+                const int K2 = (int)((tiles16 + n_single - 1) / n_single);
+                const int S2 = (int)((double)n_steps16 / ((double)(K2 - 1) + rho) + 0.5);
+                const int L2 = n_steps16 - (K2 - 1) * S2;
+                if (K2 <= 8 && S2 >= 8 && L2 >= S2) { K = K2; S = S2; L = L2; }
+            }
+            if (K == 1 && tiles16 > s->num_cu) n_single = 2LL * s->num_cu - tiles16 > 0 ? 2LL * s->num_cu - tiles16 : 0;
+            p.ybuf = p.ws;
+            p.sl_K = K; p.sl_nsingle = (int)n_single; p.sl_S = S; p.sl_L = L;
+            for (int k = 0; k < K; ++k) {
+                long long n_s = n_single > 0 ? tiles16 - (long long)k * n_single : 0;
+                n_s = n_s > n_single ? n_single : (n_s < 0 ? 0 : n_s);
+                const long long grid = n_s + (tiles16 - n_s + 1) / 2;
+                p.sl_k = k;
+                card_sample_coop16_kernel<<<dim3((unsigned)grid), dim3(kCoop2Threads), (size_t)kCoop16LdsFloats * sizeof(float), stream>>>(p);
+                HIP_TRY(hipGetLastError());
+            }
+            return CARD_OK;
+        }
         // Between one and two tiles per CU (the reference's Year minibatch: 12 800 chains = 400 tiles): the time-sliced
         // paired form, see card_sample_coop2_kernel.  n_single CUs' worth of tiles run alone in each slice; every tile
         // does so in exactly one of the K slices.  rho = the measured cost ratio of a timestep on a shared CU (9.1 us

@@ -36,6 +36,8 @@ struct card_sampler {
     float* gtab;   // (n_embed, 3, H) gamma * log2e [* bn_scale]
     float* w1s;    // hoist: packed static columns of W1
     float* ws;     // hoist: per-wave scratch slots (num_cu * 8 * 16 KB)
+    float* wpk16;  // 16-chain-tile cooperative kernel: W2 | W3 in 16x16x4 fragment order
+    float* w1s16;  // ... static columns of W1
     void* kernel;         // the back end's __global__ function for this model shape (cast back by its owner)
     size_t lds_bytes;
     // ---- GEMM back end (card_wide.hip): BN_HADAMARD, LINEAR_HADAMARD, and GUIDED at hidden != 128 or y_dim != 1

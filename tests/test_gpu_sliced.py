@@ -33,6 +33,7 @@ def _inputs(g, rows, seed):
 @pytest.mark.parametrize("N", [12800, 9001, 8224, 14336])
 def test_sliced_equals_unsliced_bit_for_bit(N, monkeypatch):
     assert 1.0 < _tiles_per_cu(N) < 2.0, "sized for a 256-CU MI355X"
+    monkeypatch.setenv("CARD_AMD_COOP16", "0")       # keep these sizes on the 32-chain kernels
     g = load_golden("reg_boston_T1000")
     s = Sampler.from_state_dict(g["sd"], device=DEV)
     T = 200                                   # the first 200 timesteps' schedule rows of the T = 1000 model
@@ -77,4 +78,59 @@ def test_sliced_full_trajectory_and_row_tiling_vs_oracle(monkeypatch):
         want = torch.stack(orc.p_sample_loop(w, tile(x), tile(y0), tile(mu), T, alphas, omabs, noise[:, sl]), 0)
         err = max(norm_rel_err(outs[0][k, sl].cpu(), want[k]) for k in range(T + 1))
         print(f"sliced kernel, row {r}: worst per-state norm-rel err vs oracle {err:.2e}")
+        assert err <= TOL
+
+
+@pytest.mark.parametrize("N", [1, 15, 16, 33, 1000, 4096, 5100, 6400, 8192])
+def test_16_chain_tile_kernel_is_bit_identical_to_the_32_chain_kernels(N, monkeypatch):
+    """card_sample_coop16_kernel (batches up to 2 x CUs x 16 chains; BASELINE configs[0] is 5 100): v_mfma_f32_16x16x4
+    fed in the 32-chain kernels' k order gives the same bits -- against the 32-chain cooperative kernel and the persistent
+    kernel, RNG and injected noise, every output mode, mid-loop segments, in-kernel row tiling, the static entry point."""
+    g = load_golden("reg_boston_T1000")
+    T = 160
+    coef = make_coef_table(g["alphas"][:T], g["omabs"][:T]).to(DEV)
+    x, y0, mu = _inputs(g, N, 11)
+    outs = {}
+    for name, env in (("coop16", {"CARD_AMD_COOP16": "1"}), ("coop32", {"CARD_AMD_COOP16": "0", "CARD_AMD_COOP2": "0"}),
+                      ("persistent", {"CARD_AMD_COOP": "0"})):
+        for k in ("CARD_AMD_COOP16", "CARD_AMD_COOP2", "CARD_AMD_COOP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        s = Sampler.from_state_dict(g["sd"], device=DEV)
+        last = s.run(x, y0, mu, coef, T, seed=31, elem_offset=5)
+        sel = s.run(x, y0, mu, coef, T, seed=31, elem_offset=5, out_mode=_lib.OUT_SELECT, states=[0, 1, 80, T])
+        seg = s.run(x, y0, mu, coef, T, seed=31, elem_offset=5, t_hi=100, t_lo=3, y_init=sel[2])
+        eps = s.eps_theta(x, sel[1], y0, 7)
+        outs[name] = (last, sel, seg, eps)
+        if name == "coop16":
+            assert torch.equal(s.run(x, y0, mu, coef, T, seed=31, elem_offset=5, static_scratch=True), last)
+    for name in ("coop32", "persistent"):
+        for a, b in zip(outs["coop16"], outs[name]):
+            assert torch.equal(a, b) and torch.isfinite(a).all(), name
+
+
+def test_16_chain_tile_kernel_year_width_and_row_tiling(monkeypatch):
+    """d_in = 92 (twelve hoisted k-groups), rows tiled in-kernel, injected noise, full trajectory: coop16 == coop32 bit
+    for bit and within 1e-4 of the oracle."""
+    g = load_golden("reg_year_T1000")
+    T, rows, n_z = 70, 51, 100                       # 5 100 chains, the Boston plumbing batch at Year's input width
+    alphas, _, omabs = orc.make_schedule("linear", T, 1e-4, 0.25)
+    coef = make_coef_table(alphas, omabs).to(DEV)
+    x, y0, mu = _inputs(g, rows, 13)
+    noise = torch.randn(T, rows * n_z, 1, generator=torch.Generator().manual_seed(14))
+    outs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CARD_AMD_COOP16", mode)
+        monkeypatch.setenv("CARD_AMD_COOP2", mode)
+        s = Sampler.from_state_dict(g["sd"], device=DEV)
+        outs.append(s.run(x, y0, mu, coef, T, noise=noise.to(DEV), out_mode=_lib.OUT_ALL, n_z=n_z))
+    assert torch.equal(outs[0], outs[1])
+    w = g["weights"]
+    for r in (0, rows - 1):
+        sl = slice(r * n_z, r * n_z + 24)
+        tile = lambda t: t[r:r + 1].cpu().repeat(24, 1)
+        want = torch.stack(orc.p_sample_loop(w, tile(x), tile(y0), tile(mu), T, alphas, omabs, noise[:, sl]), 0)
+        err = max(norm_rel_err(outs[0][k, sl].cpu(), want[k]) for k in range(T + 1))
+        print(f"16-chain kernel, row {r}: worst per-state norm-rel err vs oracle {err:.2e}")
         assert err <= TOL
