@@ -906,8 +906,10 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
     float a10[2];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) a10[mb] = g == 0 ? tab[(kOffW1 - kOffB) + 32 * w + 16 * mb + n] : 0.0f;
-    // publish: features 32w + 16mb + 4g + r go to slots 16(2w + mb) + 4(g&1) + 2(g>>1) + {0, 8, 1, 9}[r]
-    float* const exw = ex + n * kExLd + 32 * w + 4 * (g & 1) + 2 * (g >> 1);
+    // publish: features 32w + 16mb + 4g + r go to slots 16(2w + mb) + 4(g&1) + 2(g>>1) + {0, 8, 1, 9}[r].  Lanes l and
+    // l + 32 (groups g and g + 2) first trade halves (v_permlane32_swap), so that each writes ONE aligned b128 -- four
+    // slots of its own and its partner's -- instead of two b64 (which conflict two-way: rows n and n + 8 share banks)
+    float* const exw = ex + n * kExLd + 32 * w + 4 * (g & 1) + 8 * (g >> 1);
     const float* const exr = ex + n * kExLd + 4 * g;                               // + 16a: B operands of MFMAs 4a .. 4a+3
     const int T = p.T;
     const int draw0 = p.y_init ? (T - p.t_hi) : 0;
@@ -981,9 +983,15 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
     auto publish = [&](const f32x4 (&a)[2], int buf) {
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
-            float* d = exw + buf * kT16 * kExLd + 16 * mb;
-            *reinterpret_cast<float2*>(d) = float2{a[mb][0], a[mb][2]};
-            *reinterpret_cast<float2*>(d + 8) = float2{a[mb][1], a[mb][3]};
+            // lower lanes end up with (own r0, own r2, partner r0, partner r2), upper lanes with (partner r1, partner r3,
+            // own r1, own r3): v_permlane32_swap exchanges the first operand's lanes 32-63 with the second's lanes 0-31.
+            // (Inline asm: ROCm 7.2's __builtin_amdgcn_permlane32_swap loses its second result when both results feed a
+            // vector build -- tools/ubench/permlane.hip; the s_nop cover the VALU-write -> permlane read distance.)
+            float x0 = a[mb][0], x1 = a[mb][1], y0 = a[mb][2], y1 = a[mb][3];
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1"
+                         : "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1));
+            const f32x4 v = {x0, y0, x1, y1};
+            *reinterpret_cast<f32x4*>(exw + buf * kT16 * kExLd + 16 * mb) = v;
         }
     };
     auto hidden = [&](const float (&A)[64], int buf, int layer, const float* gl, f32x4 (&acc)[2]) {
