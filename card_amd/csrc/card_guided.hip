@@ -1036,16 +1036,19 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
             if (more && htid < kGammaRow / 4) *reinterpret_cast<f32x4*>(gsl + (gcur ^ 1) * kGammaRow + htid * 4) = gn;
             // lin4 in the 32-chain kernels' association: the chain over features 8q + e (q, e ascending) lives on lane
             // groups 0 -> 2 -> 0 -> 2, the one over 8q + 4 + e on 1 -> 3 -> 1 -> 3; each finished chain is added to the other
+            // (the hand-over between lanes l and l + 32 is one v_permlane32_swap instead of a ds_bpermute round trip; lane
+            // groups whose turn it is not compute on values that the next hand-over overwrites)
             float part = 0.0f;
 #pragma unroll
             for (int ph = 0; ph < 4; ++ph) {
-                if (ph > 0) part = __shfl_xor(part, 32, 64);
+                if (ph > 0) {
+                    float px = part, py = part;
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(px), "+v"(py));
+                    part = (ph & 1) ? px : py;          // odd: lanes 32-63 receive; even: lanes 0-31 receive
+                }
                 const f32x4 wv = lds4(w4l + 16 * (ph >> 1));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float nx = fmaf(acc[ph >> 1][e], wv[e], part);
-                    part = ((g >> 1) == (ph & 1)) ? nx : part;       // only the lane groups whose turn it is advance
-                }
+                for (int e = 0; e < 4; ++e) part = fmaf(acc[ph >> 1][e], wv[e], part);
             }
             part += __shfl_xor(part, 16, 64);
             if (g == 2) red[w * kT16 + n] = part;

@@ -96,14 +96,31 @@ def q_sample(y, y_0_hat, alphas_bar_sqrt, one_minus_alphas_bar_sqrt, t, noise=No
 class _StepCtx:
     """Everything the per-timestep entry points re-derive from their arguments, kept between the T calls of one loop
     (classification/card_classification.py:645-653, :665-670 call p_sample T - 1 times and p_sample_t_1to0 once with the
-    SAME model / x / y_0_hat / y_T_mean / schedule objects; only y and t change).  Holds those objects, so their ids cannot
-    be recycled while the entry lives, and two pre-filled card_run_args (steps t >= 1, and the t = 0 step with its own
-    one-row table)."""
-    __slots__ = ("model", "x", "y_0_hat", "y_T_mean", "alphas", "omabs", "sampler", "params", "versions", "in_versions",
-                 "xx", "y0", "mu", "coef", "coef0", "args", "args0", "N", "T", "seed", "last_t", "fn", "ws")
+    SAME model / x / y_0_hat / y_T_mean / schedule objects; only y and t change): the sampler, the prepared inputs and two
+    pre-filled card_run_args (steps t >= 1, and the t = 0 step with its own one-row table).  The caller's objects are held
+    through WEAK references compared by identity -- a live object cannot share its id with another, and the entry is
+    dropped the moment one of them dies -- so the context pins none of the caller's memory (x_feat of a CIFAR-10 batch is
+    410 MB); it owns only the converted copies it had to make."""
+    __slots__ = ("refs", "sampler", "params", "versions", "in_versions", "keep", "args", "args0", "N", "T", "seed",
+                 "last_t", "fn", "__weakref__")
+
+    def matches(self, objs):
+        for r, o in zip(self.refs, objs):
+            if (r() if r is not None else None) is not o:
+                return False
+        return True
 
 
 _step_ctx = None
+
+
+def _drop_step_ctx(_dead=None):
+    global _step_ctx
+    _step_ctx = None
+
+
+def _in_versions(x, y_0_hat, y_T_mean, omabs):
+    return (x._version if x is not None else 0, y_0_hat._version, y_T_mean._version, omabs._version)
 
 
 def _step_ctx_for(model, x, y_0_hat, y_T_mean, alphas, omabs, fresh):
@@ -111,10 +128,11 @@ def _step_ctx_for(model, x, y_0_hat, y_T_mean, alphas, omabs, fresh):
     re-validates the weights by identity and content (sampler_for); later steps of the loop only compare the parameters'
     version counters (a few microseconds), which catches optimizer steps / load_state_dict / in-place edits."""
     global _step_ctx
+    import ctypes as C
+    import weakref
     c = _step_ctx
-    if (c is not None and not fresh and c.model is model and c.x is x and c.y_0_hat is y_0_hat and c.y_T_mean is y_T_mean
-            and c.alphas is alphas and c.omabs is omabs
-            and c.in_versions == (x._version if x is not None else 0, y_0_hat._version, y_T_mean._version, omabs._version)):
+    objs = (model, x, y_0_hat, y_T_mean, alphas, omabs)
+    if c is not None and not fresh and c.matches(objs) and c.in_versions == _in_versions(x, y_0_hat, y_T_mean, omabs):
         for p, v in zip(c.params, c.versions):
             if p._version != v:
                 break
@@ -122,35 +140,37 @@ def _step_ctx_for(model, x, y_0_hat, y_T_mean, alphas, omabs, fresh):
             return c
     s = sampler_for(model, check_content=fresh)
     c = _StepCtx()
-    c.model, c.x, c.y_0_hat, c.y_T_mean, c.alphas, c.omabs, c.sampler = model, x, y_0_hat, y_T_mean, alphas, omabs, s
+    c.refs = tuple(weakref.ref(o, _drop_step_ctx) if o is not None else None for o in objs)
+    c.sampler = s
     from .sampler import _tensors
     c.params = _tensors(model)
     c.versions = [p._version for p in c.params]
-    c.in_versions = (x._version if x is not None else 0, y_0_hat._version, y_T_mean._version, omabs._version)
-    c.y0 = s._prep(y_0_hat, s.y_dim, "y_0_hat")
-    c.mu = s._prep(y_T_mean, s.y_dim, "y_T_mean")
-    c.N = int(c.y0.shape[0])
+    c.in_versions = _in_versions(x, y_0_hat, y_T_mean, omabs)
+    y0 = s._prep(y_0_hat, s.y_dim, "y_0_hat")
+    mu = s._prep(y_T_mean, s.y_dim, "y_T_mean")
+    c.N = int(y0.shape[0])
     need_x = s.variant != _lib.VARIANT_GUIDED or (s.cat_x and s.x_dim > 0)
-    c.xx = s._prep(_model_x(model, s, x), s.x_dim, "x") if need_x else None
-    for name, t in (("x", c.xx), ("y_T_mean", c.mu)):
+    xx = s._prep(_model_x(model, s, x), s.x_dim, "x") if need_x else None
+    for name, t in (("x", xx), ("y_T_mean", mu)):
         if t is not None and t.shape[0] != c.N:
             raise CardError(f"{name} has {t.shape[0]} rows, expected {c.N}")
     c.T = int(alphas.shape[0]) if alphas is not None else None
-    c.coef = coef_on_device(alphas, omabs, c.T, s.device) if alphas is not None else None
-    c.coef0 = _coef_row0_on_device(omabs, s.device)
-    c.ws = s._workspace(c.N)
-    import ctypes as C
+    coef = coef_on_device(alphas, omabs, c.T, s.device) if alphas is not None else None
+    coef0 = _coef_row0_on_device(omabs, s.device)
+    ws = s._workspace(c.N)
+    # what the pre-filled arguments point to and the caller does not own: converted copies, hoisted features, tables, workspace
+    c.keep = [t for t, src in ((xx, x), (y0, y_0_hat), (mu, y_T_mean)) if t is not None and t is not src] + [coef, coef0, ws[0]]
 
-    def filled(T, coef):
+    def filled(T, table):
         a = _lib.RunArgs()
         a.struct_bytes = C.sizeof(_lib.RunArgs)
         a.T, a.N, a.n_z, a.out_mode = T, c.N, 1, _lib.OUT_LAST
-        a.x, a.y_0_hat, a.y_T_mean, a.coef = _ptr(c.xx), _ptr(c.y0), _ptr(c.mu), _ptr(coef)
-        a.workspace, a.workspace_bytes = c.ws[1], c.ws[2]
+        a.x, a.y_0_hat, a.y_T_mean, a.coef = _ptr(xx), _ptr(y0), _ptr(mu), _ptr(table)
+        a.workspace, a.workspace_bytes = ws[1], ws[2]
         return a
 
-    c.args = filled(c.T, c.coef) if alphas is not None else None
-    c.args0 = filled(1, c.coef0)
+    c.args = filled(c.T, coef) if alphas is not None else None
+    c.args0 = filled(1, coef0)
     c.seed, c.last_t = None, -1
     c.fn = _lib.lib().card_sampler_run
     _step_ctx = c
@@ -195,8 +215,6 @@ def p_sample(model, x, y, y_0_hat, y_T_mean, t, alphas, one_minus_alphas_bar_sqr
     if not 1 <= t < T:
         raise CardError(f"p_sample: t={t} outside [1, {T - 1}]")
     c = _step_ctx_for(model, x, y_0_hat, y_T_mean, alphas, one_minus_alphas_bar_sqrt, fresh=(t == T - 1))
-    if c.args is None:       # context created by p_sample_t_1to0 (no alphas): complete it
-        c = _step_ctx_for(model, x, y_0_hat, y_T_mean, alphas, one_minus_alphas_bar_sqrt, fresh=True)
     if seed is None and noise is None:
         if c.seed is None or not t < c.last_t:
             c.seed = _fresh_seed()
@@ -231,12 +249,12 @@ def _coef_row0_on_device(omabs, device):
 def p_sample_t_1to0(model, x, y, y_0_hat, y_T_mean, one_minus_alphas_bar_sqrt):
     """regression/diffusion_utils.py:94-104: the last step (timestep index 0), no noise."""
     c = _step_ctx
-    if not (c is not None and c.model is model and c.x is x and c.y_0_hat is y_0_hat and c.y_T_mean is y_T_mean
-            and c.omabs is one_minus_alphas_bar_sqrt):
-        # not the tail of a p_sample loop over the same objects: build a context of its own (no alphas -> t = 0 only)
-        c = _step_ctx_for(model, x, y_0_hat, y_T_mean, None, one_minus_alphas_bar_sqrt, fresh=True)
+    alphas = c.refs[4]() if (c is not None and c.refs[4] is not None) else None
+    if c is not None and c.matches((model, x, y_0_hat, y_T_mean, alphas, one_minus_alphas_bar_sqrt)):
+        # the tail of a p_sample loop over the same objects: reuse its context (weights re-checked by version counters)
+        c = _step_ctx_for(model, x, y_0_hat, y_T_mean, alphas, one_minus_alphas_bar_sqrt, fresh=False)
     else:
-        c = _step_ctx_for(model, x, y_0_hat, y_T_mean, c.alphas, one_minus_alphas_bar_sqrt, fresh=False)
+        c = _step_ctx_for(model, x, y_0_hat, y_T_mean, None, one_minus_alphas_bar_sqrt, fresh=True)
     c.last_t = 0
     return _step_run(c, c.args0, y, 0, None, 0, 0)
 

@@ -366,6 +366,8 @@ def x_features(model, x):
     theta = _imagenet_theta(model)
     with torch.no_grad():
         xf = (theta.linx(x) if theta is not None else model.norm(model.encoder_x(x))).float().contiguous()
+    if xf is x:                  # identity encoder: nothing was computed, and caching x under its own weak key would pin it
+        return xf
     mref = weakref.ref(model)
 
     def _drop(_, mref=mref):

@@ -360,3 +360,38 @@ def test_f128_time_sliced_two_tile_form_is_bit_identical(rows, n_z, C, monkeypat
         err = norm_rel_err(got[sl_], want)
         print(f"sliced cls kernel rows={rows} n_z={n_z} C={C}, row {r}: norm-rel err vs oracle {err:.2e}")
         assert err <= TOL
+
+
+def test_per_timestep_shim_loop_equals_fused_loop_and_pins_nothing():
+    """The reference's p_sample_loop_only_y_0 shape (classification/card_classification.py:656-671: T - 1 calls of
+    p_sample, one of p_sample_t_1to0) through the shim's cached call context: with the same seed it reproduces the fused
+    loop bit for bit (noise is keyed by (seed, element, draw)), picks up an in-place weight edit between two loops, and
+    does not keep the caller's tensors alive."""
+    import gc
+    import weakref
+    from card_amd import diffusion_utils as du
+    g = load_golden("cls_mnist_T50")
+    m = RefShapedCls(g["sd"]).to(DEV).eval()
+    T = g["T"]
+    al, om = cuda(g["alphas"]), cuda(g["omabs"])
+    xf, y0 = cuda(g["x_feat"]), cuda(g["y0hat"])
+
+    def stepwise(seed):
+        cur = card_amd.p_sample_loop(m, xf, y0, y0, T, al, om, seed=seed, states=[0])[0]
+        for t in reversed(range(1, T)):
+            cur = card_amd.p_sample(m, xf, cur, y0, y0, t, al, om, seed=seed)
+        return card_amd.p_sample_t_1to0(m, xf, cur, y0, y0, om)
+
+    want = card_amd.p_sample_loop(m, xf, y0, y0, T, al, om, True, seed=77)
+    assert torch.equal(stepwise(77), want)
+    assert du._step_ctx is not None and du._step_ctx.matches((m, xf, y0, y0, al, om))
+    # an EMA-style copy behind the version counters between two loops: the first step of the next loop re-packs
+    with torch.no_grad():
+        m.lin4.weight.data.copy_(m.lin4.weight.data * 1.25)
+    got = stepwise(77)
+    assert not torch.equal(got, want) and torch.equal(got, card_amd.p_sample_loop(m, xf, y0, y0, T, al, om, True, seed=77))
+    # the context holds the caller's tensors weakly: dropping x frees it and clears the context
+    ref = weakref.ref(xf)
+    del xf
+    gc.collect()
+    assert ref() is None and du._step_ctx is None
