@@ -523,7 +523,9 @@ int clscoop_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
         p.n_seg = n_seg;
         const long long slots = nt * n_seg;
         // a slice must not hold two segments of one tile: slices of at most nt slots (P <= nt whenever n_seg > 1)
-        const long long per = n_seg > 1 ? P : (nt < P ? nt : P);
+        // (un-sliced: ONE launch of all tile pairs -- the dispatcher walks them num_cu workgroups at a time; short calls
+        // such as the reference's per-timestep p_sample are launch- and prologue-bound, so fewer launches win)
+        const long long per = n_seg > 1 ? P : slots;
         for (long long q0 = 0; q0 < slots; q0 += per) {
             p.q0 = q0;
             p.q1 = q0 + per < slots ? q0 + per : slots;
