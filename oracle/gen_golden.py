@@ -201,25 +201,57 @@ def gen_regression(reg_du, reg_model, name, x_dim, T, sched, N, seed, cat_x=True
     print(f"{name}: N={N} T={T} d_in={model.lin1.lin.weight.shape[1]} max|y|={traj.abs().max():.3f}")
 
 
-def gen_classification(cls_du, cls_model, name, dataset, data_dim, C, Fdim, T, N, seed, lin4_scale=0.1):
+def train_cls_model(cls_du, model, data_dim, C, T, abs_, omabs, steps, seed):
+    """A short run of the reference's classification noise-estimation loss (classification/card_classification.py:
+    y one-hot, y_0_hat = the guidance classifier's softmax, e ~ N(0,1), y_t = q_sample(y, y_0_hat, ..., t, noise=e),
+    loss = (e - model(x, y_t, t, y_0_hat))^2.mean()) on a synthetic linearly separable task, in train mode so that the
+    BatchNorm running statistics are the trained ones: the T = 1000 trajectories then stay O(1) like a trained CARD's."""
+    g = torch.Generator().manual_seed(seed)
+    Wc = torch.randn(data_dim, C, generator=g) / data_dim ** 0.5
+    torch.manual_seed(seed)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    model.train()
+    for it in range(steps):
+        x = torch.randn(256, data_dim)
+        logits = x @ Wc * 3.0
+        y = torch.nn.functional.one_hot(logits.argmax(1), C).float()
+        y0hat = torch.softmax(logits + 0.5 * torch.randn(256, C), 1)
+        t = torch.randint(0, T, (256,))
+        e = torch.randn_like(y)
+        y_t = cls_du.q_sample(y, y0hat, abs_, omabs, t, noise=e)
+        loss = (e - model(x, y_t, t, y0hat)).square().mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    model.eval()
+    return float(loss.detach()), Wc
+
+
+def gen_classification(cls_du, cls_model, name, dataset, data_dim, C, Fdim, T, N, seed, lin4_scale=0.1, train_steps=0):
     torch.manual_seed(seed)
     cfg = NS(diffusion=NS(timesteps=T),
              model=NS(data_dim=data_dim, arch="linear", feature_dim=Fdim, hidden_dim=Fdim),
              data=NS(num_classes=C, dataset=dataset))
     model = cls_model.ConditionalModel(cfg, guidance=True)
-    with torch.no_grad():
-        model.lin4.weight.mul_(lin4_scale)
-        model.lin4.bias.mul_(lin4_scale)
-        for m in model.modules():               # non-trivial eval-mode BatchNorm statistics
-            if isinstance(m, torch.nn.BatchNorm1d):
-                m.running_mean.normal_(0, 0.3)
-                m.running_var.uniform_(0.5, 1.5)
-                m.weight.uniform_(0.7, 1.3)
-                m.bias.normal_(0, 0.2)
-    model.eval()
     alphas, abs_, omabs = schedule(cls_du, "linear", T, 1e-4, 0.02 if T >= 500 else 0.4)
+    Wc = None
+    if train_steps:
+        loss, Wc = train_cls_model(cls_du, model, data_dim, C, T, abs_, omabs, train_steps, seed)
+        print(f"  trained {train_steps} steps, loss {loss:.4f}")
+    else:
+        with torch.no_grad():
+            model.lin4.weight.mul_(lin4_scale)
+            model.lin4.bias.mul_(lin4_scale)
+            for m in model.modules():               # non-trivial eval-mode BatchNorm statistics
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.running_mean.normal_(0, 0.3)
+                    m.running_var.uniform_(0.5, 1.5)
+                    m.weight.uniform_(0.7, 1.3)
+                    m.bias.normal_(0, 0.2)
+    model.eval()
+    torch.manual_seed(seed + 7)
     x = torch.randn(N, data_dim)
-    y0hat = torch.softmax(torch.randn(N, C) * 2, dim=1)
+    y0hat = torch.softmax(x @ Wc * 3.0 + 0.5 * torch.randn(N, C), 1) if train_steps else torch.softmax(torch.randn(N, C) * 2, dim=1)
     yTmean = y0hat.clone()
     with torch.no_grad():
         x_feat = model.norm(model.encoder_x(x))          # hoisted, classification/model.py:80-81
@@ -410,9 +442,10 @@ def main():
     R("reg_boston_T1000", 13, 1000, T1000, 32, 17, keep_every=50, train_steps=4000)
     R("reg_toy_T1000", 1, 1000, T1000, 32, 19, keep_every=50, train_steps=4000)      # BASELINE configs[1] shape, d_in = 3
     R("reg_year_T1000", 90, 1000, T1000, 32, 20, keep_every=50, train_steps=4000)    # BASELINE configs[2] shape, d_in = 92
-    K = lambda name, *a: job(name, gen_classification, cls_du, cls_model, name, *a)
+    K = lambda name, *a, **k: job(name, gen_classification, cls_du, cls_model, name, *a, **k)
     K("cls_gaussmix_T50", "toy", 1, 3, 128, 50, 24, 21)
     K("cls_mnist_T50", "MNIST", 784, 10, 128, 50, 20, 22)
+    K("cls_mnist_T1000", "MNIST", 784, 10, 128, 1000, 8, 25, train_steps=2500)          # classification/configs/mnist.yml: T = 1000, beta 1e-4 .. 0.02
     S = lambda name, *a: job(name, gen_classification_synth, cls_du, cls_model, name, *a)
     S("clsw_cifar10_T50", "CIFAR10", 3072, 10, 4096, 50, 24, 23)       # classification/configs/cifar10.yml:15-19
     S("clsw_c100_T50", "CIFAR100", 64, 100, 256, 50, 24, 24)

@@ -122,20 +122,22 @@ def test_metric_sums_over_states_and_finalize():
         assert abs(float(fin["nll"][k]) - nll.mean()) < 1e-4
 
 
-def test_end_to_end_metrics_within_seed_to_seed_variance():
+@pytest.mark.parametrize("name,n_z,reps,slack", [("reg_boston_T50", 400, 12, 1.0), ("reg_boston_T1000", 100, 6, 2.0)])
+def test_end_to_end_metrics_within_seed_to_seed_variance(name, n_z, reps, slack):
     """north_star, end-to-end level: with in-kernel RNG, RMSE / NLL / PICP / QICE of the HIP path (sampling + on-device
     metrics) match the reference pipeline (oracle sampling driven by torch.randn + the numpy restatement of the
-    reference's metric helpers) within the spread the reference shows between two seeds of its own."""
+    reference's metric helpers) within the spread the reference shows between two seeds of its own.  Both the T = 50
+    fixture model and the T = 1000 one (the UCI configs' schedule, regression/configs/uci_boston.yml:24-27)."""
     from card_amd import _lib
     from card_amd.sampler import Sampler, make_coef_table
     from oracle import card_oracle as orc
     from tests.helpers import load_golden
-    g = load_golden("reg_boston_T50")                 # trained fixture model, T = 50
-    T, n_z, n_bins = g["T"], 400, 10
-    reps = 12                                         # 40 fixture rows x 12 perturbed copies = 480 test rows
+    g = load_golden(name)                             # trained fixture model
+    T, n_bins = g["T"], 10
+    base = g["x"].shape[0]                            # fixture rows x perturbed copies = test rows
     gen = torch.Generator().manual_seed(77)
-    x = g["x"].repeat(reps, 1) + 0.05 * torch.randn(40 * reps, g["x"].shape[1], generator=gen)
-    y0 = g["y0hat"].repeat(reps, 1) + 0.05 * torch.randn(40 * reps, 1, generator=gen)
+    x = g["x"].repeat(reps, 1) + 0.05 * torch.randn(base * reps, g["x"].shape[1], generator=gen)
+    y0 = g["y0hat"].repeat(reps, 1) + 0.05 * torch.randn(base * reps, 1, generator=gen)
     rows = x.shape[0]
     tile = lambda t: t.repeat_interleave(n_z, 0)
 
@@ -162,7 +164,7 @@ def test_end_to_end_metrics_within_seed_to_seed_variance():
     coef = make_coef_table(g["alphas"], g["omabs"]).to(DEV)
     y = s.run(x.to(DEV), y0.to(DEV), y0.to(DEV), coef, T, seed=2024, n_z=n_z)
     fin = metrics.finalize(metrics.regression_metric_sums(y.reshape(rows, n_z, 1), y_true.to(DEV), n_bins=n_bins), n_bins)
-    floor = {"rmse": 0.02, "nll": 0.03, "picp": 0.02, "qice": 0.01}     # sampling-error floor at 480 rows x 400 samples
+    floor = {k: v * slack for k, v in {"rmse": 0.02, "nll": 0.03, "picp": 0.02, "qice": 0.01}.items()}   # sampling-error floor at 480 rows x 400 samples (x2 at 192 x 100)
     for k in ("rmse", "nll", "picp", "qice"):
         hip, spread = float(fin[k][0]), abs(a[k] - b[k])
         print(f"{k}: hip {hip:.4f}  reference seeds {a[k]:.4f} / {b[k]:.4f}")
