@@ -5,7 +5,13 @@ import collections, csv, glob, json, os, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 os.makedirs("profiles", exist_ok=True)
 if os.path.exists("gpurun_out/ubench.txt"):
-    open(f"profiles/{tag}_ubench.txt", "w").write(open("gpurun_out/ubench.txt").read())
+    # keep the hand-written notes (everything from the first dashed rule on) when the measurements are refreshed
+    dst, note = f"profiles/{tag}_ubench.txt", ""
+    if os.path.exists(dst):
+        old = open(dst).read()
+        cut = old.find("\n" + "-" * 70)
+        note = old[cut:] if cut >= 0 else ""
+    open(dst, "w").write(open("gpurun_out/ubench.txt").read() + note)
 
 for name in ("bench", "cifar", "stream", "mnist"):
     for p in glob.glob(f"gpurun_out/prof_{name}/*/*kernel_stats.csv"):
