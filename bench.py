@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3       # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MATRIX_TFLOPS = 2500.0      # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA" (dense); priced against only by --arith split
 TILE_M, WAVES_PER_CU, TILES_PER_WAVE_PER_LAUNCH = 32, 8, 16   # guided_run() chunking in card_amd/csrc/card_guided.hip
 
 
@@ -80,6 +81,9 @@ def main():
     ap.add_argument("--x-dim", type=int, default=None)
     ap.add_argument("--hidden", type=int, default=None, help="hidden width (128: persistent kernel; other multiples of 128: GEMM back end)")
     ap.add_argument("--T", type=int, default=1000)
+    ap.add_argument("--arith", default="f32", choices=["f32", "split"],
+                    help="f32 = FP32 MFMA (default, the headline line); split = CARD_ARITH_SPLIT_BF16: the hidden layers as six "
+                         "bf16 MFMAs per k-step on exact three-way bf16 cuts of the fp32 operands (hidden-128 regression only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -134,6 +138,9 @@ def main():
         x_rows = torch.randn(a.rows, H, generator=g)
         y0_rows = torch.softmax(torch.randn(a.rows, y_dim, generator=g) * 2, 1)
         y_true = None
+    arith = _lib.ARITH_SPLIT_BF16 if a.arith == "split" else _lib.ARITH_F32_MFMA
+    if arith == _lib.ARITH_SPLIT_BF16 and not (kind == "guided" and H == 128 and y_dim == 1):
+        sys.exit("--arith split is built for the hidden-128 regression sampler")
     persistent = kind == "guided" and H in (128, 256)     # card_guided.hip / card_stream.hip; otherwise GEMM back end
     cls_coop = kind == "cls" and H == 128 and y_dim <= 32  # card_clscoop.hip
     x, y0 = x_rows.to(dev), y0_rows.to(dev)
@@ -142,7 +149,8 @@ def main():
     from card_amd.metrics import regression_metric_sums
 
     def one_step(i):
-        y = sampler.run(x, y0, y0, coef, T, seed=1234 + i, elem_offset=elem_offset, out_mode=_lib.OUT_LAST, n_z=a.nz)
+        y = sampler.run(x, y0, y0, coef, T, seed=1234 + i, elem_offset=elem_offset, out_mode=_lib.OUT_LAST, n_z=a.nz,
+                        arith=arith)
         if use_dist:
             # evaluation sums of this rank's rows, then ONE small RCCL all-reduce per loop -- the only collective
             if kind == "guided":
@@ -191,7 +199,11 @@ def main():
             chunk = cu * WAVES_PER_CU * TILES_PER_WAVE_PER_LAUNCH * TILE_M if H == 128 else cu * 8 * 128   # guided_run / stream_run
             launches = math.ceil(N / chunk) * a.steps
             kernel = "card_sample_guided_kernel" if H == 128 else "card_sample_stream_kernel"
-            if H == 128 and N <= 7 * cu * 32:
+            if arith == _lib.ARITH_SPLIT_BF16:
+                chunk = cu * 96 * 3 * 32                       # split_run(): 96 groups of three 32-chain tiles per CU and launch
+                launches = math.ceil(N / chunk) * a.steps
+                kernel = "card_sample_split_kernel"
+            elif H == 128 and N <= 7 * cu * 32:
                 # guided_run(): small batches run on the cooperative kernels, between one and two tiles per CU time-sliced
                 def slices(tiles, rho):
                     if not cu < tiles < 2 * cu or T < 64:
@@ -264,6 +276,17 @@ def main():
                          "frac_executed": achieved_exec / PEAK_FP32_MATRIX_TFLOPS,
                          "launches": launches, "avg_launch_ms": avg_launch_ms},
         }
+        if arith == _lib.ARITH_SPLIT_BF16:
+            # opt-in arithmetic, not the headline: the two hidden layers run as 6 bf16 MFMAs per 16-deep k-step, so the
+            # matrix pipe that bounds this kernel is the bf16 one; `achieved` = the bf16 flops it issues
+            ex_bf16 = 6 * 2 * H * (2 * H)
+            ach = (float(N) * T * a.steps * ex_bf16) / (ev_ms * 1e-3) / 1e12
+            out["arith"] = "split_bf16 (CARD_ARITH_SPLIT_BF16: fp32 operands cut exactly into 3 bf16 parts, fp32 accumulation)"
+            out["roofline"].update({"achieved": ach, "peak": PEAK_BF16_MATRIX_TFLOPS, "frac": ach / PEAK_BF16_MATRIX_TFLOPS,
+                                    "flops_executed_per_sample_step": ex_bf16, "achieved_executed": ach,
+                                    "frac_executed": ach / PEAK_BF16_MATRIX_TFLOPS, "traffic": None,
+                                    "algorithmic_fp32_tflops": achieved,
+                                    "algorithmic_over_fp32_matrix_peak": achieved / PEAK_FP32_MATRIX_TFLOPS})
         if world == 1 and not a.no_cpu_baseline:
             threads = torch.get_num_threads()
             from oracle import card_oracle as orc

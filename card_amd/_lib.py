@@ -8,6 +8,7 @@ LIB_PATH = os.environ.get("CARD_AMD_LIB") or os.path.join(_HERE, "libcard_hip.so
 CARD_OK = 0
 VARIANT_GUIDED, VARIANT_BN_HADAMARD, VARIANT_LINEAR_HADAMARD = 0, 1, 2
 OUT_LAST, OUT_ALL, OUT_SELECT = 0, 1, 2
+ARITH_F32_MFMA, ARITH_SPLIT_BF16 = 0, 1
 COEF_COLS = 8
 
 EXPORTS = (
@@ -37,7 +38,7 @@ class RunArgs(C.Structure):
         ("N", C.c_int64), ("x", _fp), ("y_0_hat", _fp), ("y_T_mean", _fp), ("y_init", _fp), ("coef", _fp),
         ("noise", _fp), ("seed", C.c_uint64), ("elem_offset", C.c_uint64), ("out", _fp),
         ("out_mode", C.c_int32), ("n_z", C.c_int32), ("state_slot", _fp), ("workspace", _fp), ("workspace_bytes", C.c_uint64),
-        ("fphi", _fp), ("fphi_out", _fp),
+        ("fphi", _fp), ("fphi_out", _fp), ("arith", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

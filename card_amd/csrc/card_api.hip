@@ -244,6 +244,10 @@ static int sampler_run(const card_sampler* s, const card_run_args* a, void* stre
     r.N = a->N; r.seed = a->seed; r.elem_offset = a->elem_offset;
     r.T = a->T; r.t_hi = a->t_hi; r.t_lo = a->t_lo; r.out_mode = a->out_mode; r.eps_only = 0;
     r.n_z = a->n_z > 1 ? a->n_z : 1;
+    if (a->arith != CARD_ARITH_F32_MFMA && a->arith != CARD_ARITH_SPLIT_BF16) return fail(CARD_E_INVALID, "card_sampler_run: unknown arith %d", a->arith);
+    if (a->arith == CARD_ARITH_SPLIT_BF16 && s->backend != 0)
+        return fail(CARD_E_UNSUPPORTED, "card_sampler_run: CARD_ARITH_SPLIT_BF16 is built for GUIDED samplers at hidden 128, y_dim 1");
+    r.arith = a->arith;
     if (lib_scratch) {
         r.workspace = lib_scratch; r.workspace_bytes = lib_scratch_bytes; r.lib_scratch = 1;
     }

@@ -1213,6 +1213,8 @@ int guided_create(card_sampler* s, const card_model_desc* d, hipStream_t stream)
     }
     pack_hidden_kernel<<<kH * kH / 256, 256, 0, stream>>>(d->W[1], kLn2, s->wpk + kOffW2);
     pack_hidden_kernel<<<kH * kH / 256, 256, 0, stream>>>(d->W[2], kLn2, s->wpk + kOffW3);
+    if (hoist)
+        if (int rc = split_create(s, d, stream)) return rc;      // CARD_ARITH_SPLIT_BF16 (reads the hoisted image's small tables)
     if (hoist) {
         pack_col0_kernel<<<1, kH, 0, stream>>>(d->W[0], d_in, s->wpk + kOffW1);
         if (nqs > 0) pack_static_kernel<<<(kH * 8 * nqs + 255) / 256, 256, 0, stream>>>(d->W[0], d_in, nqs, s->w1s);
@@ -1233,9 +1235,17 @@ void guided_destroy(card_sampler* s) {
     if (s->ws) (void)hipFree(s->ws);
     if (s->wpk16) (void)hipFree(s->wpk16);
     if (s->w1s16) (void)hipFree(s->w1s16);
+    split_destroy(s);
 }
 
 int guided_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
+    int arith = r.arith;
+    if (arith == CARD_ARITH_F32_MFMA)
+        if (const char* av = getenv("CARD_AMD_ARITH")) arith = av[0] == 's' ? CARD_ARITH_SPLIT_BF16 : arith;
+    if (arith == CARD_ARITH_SPLIT_BF16) {
+        if (!s->wsplit) return card_fail(CARD_E_UNSUPPORTED, "card_sampler_run: CARD_ARITH_SPLIT_BF16 needs the hoisted layer-1 image (CARD_AMD_HOIST=0 is set)");
+        return split_run(s, r, stream);
+    }
     RunParams p;
     memset(&p, 0, sizeof(p));
     p.wpk = s->wpk; p.gtab = s->gtab; p.coef = r.coef; p.x = r.x; p.y0hat = r.y0hat; p.ytmean = r.ytmean;

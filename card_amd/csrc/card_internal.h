@@ -19,6 +19,7 @@ struct CardRun {
     unsigned long long seed, elem_offset;
     int T, t_hi, t_lo, out_mode, eps_only;
     int n_z;                // >= 1: chains per input row
+    int arith;              // card_arith
     int lib_scratch;        // card_sampler_run_static: `workspace` is the library's per-GPU static array, to be used
                             // for every scratch buffer of the back end (also in place of the sampler's own slots)
 };
@@ -38,6 +39,7 @@ struct card_sampler {
     float* ws;     // hoist: per-wave scratch slots (num_cu * 8 * 16 KB)
     float* wpk16;  // 16-chain-tile cooperative kernel: W2 | W3 in 16x16x4 fragment order
     float* w1s16;  // ... static columns of W1
+    unsigned short* wsplit;   // card_split.hip: bf16 parts of W2 | W3 in A-fragment order (also uses W1 below, raw)
     void* kernel;         // the back end's __global__ function for this model shape (cast back by its owner)
     size_t lds_bytes;
     // ---- GEMM back end (card_wide.hip): BN_HADAMARD, LINEAR_HADAMARD, and GUIDED at hidden != 128 or y_dim != 1
@@ -52,6 +54,11 @@ struct card_sampler {
 int guided_create(card_sampler* s, const card_model_desc* d, hipStream_t stream);
 void guided_destroy(card_sampler* s);
 int guided_run(const card_sampler* s, const CardRun& r, hipStream_t stream);
+
+// card_split.hip: CARD_ARITH_SPLIT_BF16 for backend 0 (shares wpk's small tables, gtab)
+int split_create(card_sampler* s, const card_model_desc* d, hipStream_t stream);
+void split_destroy(card_sampler* s);
+int split_run(const card_sampler* s, const CardRun& r, hipStream_t stream);
 
 int wide_create(card_sampler* s, const card_model_desc* d, hipStream_t stream);
 void wide_destroy(card_sampler* s);

@@ -174,7 +174,8 @@ class Sampler:
         return t
 
     def run(self, x, y_0_hat, y_T_mean, coef, T, *, t_hi=None, t_lo=0, y_init=None, noise=None, seed=0,
-            elem_offset=0, out_mode=_lib.OUT_LAST, states=None, n_z=1, static_scratch=False, fphi=None, fphi_out=None):
+            elem_offset=0, out_mode=_lib.OUT_LAST, states=None, n_z=1, static_scratch=False, fphi=None, fphi_out=None,
+            arith=_lib.ARITH_F32_MFMA):
         """card_sampler_run.  Returns (N, y_dim) for OUT_LAST, (n_states, N, y_dim) otherwise.
         n_z > 1: x / y_0_hat / y_T_mean are per test ROW and every row is expanded to n_z chains inside the
         kernel (N = rows * n_z, chain order (row, z) like regression/card_regression.py:1027-1035).
@@ -182,7 +183,9 @@ class Sampler:
         static array, no workspace is passed (the output tensor is still torch's).
         fphi = a card_amd.guidance.GuidanceNet: y_0_hat = f_phi(x) is computed inside the call (first kernel) into
         `fphi_out` ((rows, y_dim), allocated when None; kept as self.last_y_0_hat); y_0_hat is ignored and y_T_mean=None
-        means y_T_mean = y_0_hat (regression/card_regression.py:1021-1035)."""
+        means y_T_mean = y_0_hat (regression/card_regression.py:1021-1035).
+        arith = _lib.ARITH_SPLIT_BF16: the hidden layers on the bf16 matrix pipe at fp32 accuracy (card_arith in
+        include/card_hip.h; regression samplers at hidden 128 only)."""
         T = int(T)
         t_hi = T - 1 if t_hi is None else int(t_hi)
         t_lo = int(t_lo)
@@ -251,6 +254,7 @@ class Sampler:
         a.coef, a.noise = _ptr(coef), _ptr(nz)
         a.seed, a.elem_offset = int(seed) & (2 ** 64 - 1), int(elem_offset)
         a.out, a.out_mode, a.state_slot, a.n_z = _ptr(out), out_mode, _ptr(slot), n_z
+        a.arith = int(arith)
         if fphi is not None:
             a.fphi, a.fphi_out = fphi._h, _ptr(fphi_out)
         L = _lib.lib()

@@ -62,6 +62,23 @@ typedef enum card_out_mode {
     CARD_OUT_SELECT = 2 /* out is (n_slots, N, y_dim): state s goes to slot state_slot[s], skipped when < 0 */
 } card_out_mode;
 
+/* Arithmetic of the two hidden-width matrix products of a timestep (card_run_args.arith).  Everything else -- layer 1,
+ * gamma / softplus, lin4, the posterior update, the noise -- is fp32 on the vector ALU in both.
+ * NO COUNTERPART IN THE REFERENCE (its addmm is plain fp32). */
+typedef enum card_arith {
+    /* v_mfma_f32_32x32x2_f32: fp32 operands, fp32 accumulation.  The default, and what every published number of this
+       library is measured with unless it says otherwise. */
+    CARD_ARITH_F32_MFMA = 0,
+    /* Every fp32 operand is cut EXACTLY into three bf16 numbers (8 + 8 + 8 significant bits) and the product is formed
+       from the six largest of the nine partial products on v_mfma_f32_32x32x16_bf16 (exact bf16 x bf16 products, fp32
+       accumulation); the dropped terms are below 2^-24 |a||b|.  Measured error of a K = 128 dot product: below the
+       FP32 MFMA chain's (tools/ubench/splitbf16.hip).  GUIDED samplers at hidden 128, y_dim 1 only (card_split.hip);
+       CARD_E_UNSUPPORTED elsewhere.  Not bit-identical to CARD_ARITH_F32_MFMA (a different, equally accurate
+       rounding); same RNG streams.  The environment variable CARD_AMD_ARITH=split selects it for calls that leave
+       arith at 0. */
+    CARD_ARITH_SPLIT_BF16 = 1
+} card_arith;
+
 /* Columns of one row of the (T, 8) coefficient table (card_make_coef_table). */
 enum {
     CARD_COEF_INV_SQRT_AB = 0,
@@ -177,6 +194,8 @@ typedef struct card_run_args {
                                zeros for config.diffusion.noise_prior (:1032-1033). */
     float* fphi_out;        /* device (rows, y_dim), required with fphi: receives y_0_hat = f_phi(x) (the caller's metrics need
                                it too, and so the call allocates nothing) */
+    int32_t arith;          /* card_arith: how the hidden-layer products are formed (0 = the default, FP32 MFMA) */
+    int32_t reserved0;      /* 0 */
 } card_run_args;
 
 /* Run timesteps t_hi ... t_lo of the reverse process for N independent chains (persistent kernels: one launch per
