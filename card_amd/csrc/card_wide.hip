@@ -28,74 +28,86 @@ constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 4;
 constexpr int kStageFloats = (BM + BN) * LDT;
 constexpr int kGemmLds = 2 * kStageFloats * (int)sizeof(float);   // 73 728 B -> two blocks per CU
 
+constexpr int kHeadFusedMaxC = 32;     // wide_head_update_kernel
 enum { EPI_SOFTPLUS = 0, EPI_BIAS = 1, EPI_SOFTPLUS_MUL = 2, EPI_SCALE = 3, EPI_SCALE_MUL = 4 };
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void wide_gemm_kernel(const float* __restrict__ A, const float* __restrict__ W,
-                                                           const float* __restrict__ bias, const float* __restrict__ g,
-                                                           const float* __restrict__ sh, const float* __restrict__ mul,
-                                                           int mul_div, float* __restrict__ out, long long M, int K,
-                                                           int ldo) {
+// TBM = TBN = 128: the 128 x 128 block tile (4 waves as 2 x 2, each 2 x 2 MFMA tiles).  TBM = TBN = 64: 64 x 64 (each wave one
+// tile, two workgroups per CU), same k loop, for the last, partly filled round of a launch: the reference's test minibatch of 250 images x 100 z
+// is 196 row blocks x 32 column blocks = 12.25 rounds of 512 resident workgroups, and the 128 tiles of the last quarter
+// round used to cost 0.57 of a full round (each alone on a CU: one wave per SIMD hides neither the barrier nor the load latency); as four times as many 64 x 64
+// tiles, two per CU, they cost about half that.  Every output
+// element is the same fp32 FMA chain over k in either shape, so which shape computes a row changes no bits.
+template <int EPI, int TBM, int TBN>
+__device__ __forceinline__ void wide_gemm_tile(const float* __restrict__ A, const float* __restrict__ W,
+                                               const float* __restrict__ bias, const float* __restrict__ g,
+                                               const float* __restrict__ sh, const float* __restrict__ mul,
+                                               int mul_div, float* __restrict__ out, long long M, int K,
+                                               int ldo, long long m_first, int bx, long long by) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int TM = TBM / 64, TN = TBN / 64;                // MFMA tiles per wave along the rows / columns
+    constexpr int kStage = (TBM + TBN) * LDT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, hh = lane >> 5;
-    const long long m0 = (long long)blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
-    // staging map: 8 threads cover one 128-byte row segment, 32 rows per pass, 4 passes per operand.  Both panels
+    const long long m0 = m_first + by * TBM;
+    const int n0 = bx * TBN;
+    // staging map: 8 threads cover one 128-byte row segment, 32 rows per pass, 4 passes per 128 rows.  Both panels
     // are read through buffer resources (base = this block's first row, scalar k offset): the k loop carries no
     // per-lane address arithmetic, and rows past M read as zero (num_records) instead of being clamped.
     const int sr = tid >> 3, sc = (tid & 7) * 4;
-    const long long rows_a = M - m0 < BM ? M - m0 : BM;
+    const long long rows_a = M - m0 < TBM ? M - m0 : TBM;
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + m0 * K), 0, (int)(rows_a * K * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W + (long long)n0 * K), 0, BN * K * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W + (long long)n0 * K), 0, TBN * K * 4, 0x00020000);
     int vo[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) vo[i] = ((sr + 32 * i) * K + sc) * 4;
-    f32x4 ra[4], rw[4];
+    f32x4 ra[2 * TM], rw[2 * TN];
     auto g_load = [&](int kt) {
         const int so = kt * BK * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo[i], so, 0));
-            rw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, vo[i], so, 0));
+            if (i < 2 * TM) ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo[i], so, 0));
+            if (i < 2 * TN) rw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, vo[i], so, 0));
         }
     };
     float* const st_base = sm + sr * LDT + sc;
     auto s_store = [&](int st) {
-        float* As = st_base + st * kStageFloats;
-        float* Ws = As + BM * LDT;
+        float* As = st_base + st * kStage;
+        float* Ws = As + TBM * LDT;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(As + 32 * i * LDT) = ra[i];
-            *reinterpret_cast<f32x4*>(Ws + 32 * i * LDT) = rw[i];
+            if (i < 2 * TM) *reinterpret_cast<f32x4*>(As + 32 * i * LDT) = ra[i];
+            if (i < 2 * TN) *reinterpret_cast<f32x4*>(Ws + 32 * i * LDT) = rw[i];
         }
     };
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-    const float* const a_base = sm + (wm * 64 + li) * LDT + 4 * hh;
-    const float* const w_base = sm + BM * LDT + (wn * 64 + li) * LDT + 4 * hh;
+    const float* const a_base = sm + (wm * 32 * TM + li) * LDT + 4 * hh;
+    const float* const w_base = sm + TBM * LDT + (wn * 32 * TN + li) * LDT + 4 * hh;
     // one 32-deep k tile from LDS stage `st` (a literal at both call sites: every LDS offset is an immediate)
     auto compute = [&](int st) {
-        const float* As = a_base + st * kStageFloats;
-        const float* Ws = w_base + st * kStageFloats;
+        const float* As = a_base + st * kStage;
+        const float* Ws = w_base + st * kStage;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(As + 8 * t);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(As + 32 * LDT + 8 * t);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(Ws + 8 * t);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(Ws + 32 * LDT + 8 * t);
+            f32x4 af[TM];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const f32x4*>(As + a * 32 * LDT + 8 * t);
+            f32x4 bf[TN];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bf[b] = *reinterpret_cast<const f32x4*>(Ws + b * 32 * LDT + 8 * t);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][e], bf[b][e], acc[a][b], 0, 0, 0);
             }
         }
     };
@@ -123,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void wide_gemm_kernel(const float* __restri
     // one per element: table in LDS (the tiles are dead after the loop's last barrier)
     int* mrow = reinterpret_cast<int*>(sm);
     if (EPI == EPI_SOFTPLUS_MUL || EPI == EPI_SCALE_MUL) {
-        if (tid < BM) {
+        if (tid < TBM) {
             long long r = m0 + tid;
             if (r > M - 1) r = M - 1;
             mrow[tid] = (int)(r / mul_div);
@@ -132,16 +144,16 @@ __global__ __launch_bounds__(256, 2) void wide_gemm_kernel(const float* __restri
     }
     // epilogue: C/D map of the 32x32 tile: column = lane & 31 (feature), row = (r&3) + 8(r>>2) + 4(lane>>5) (chain)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int col = n0 + wn * 64 + b * 32 + li;
+    for (int b = 0; b < TN; ++b) {
+        const int col = n0 + wn * 32 * TN + b * 32 + li;
         const float bb = bias[col];
         float gg = 0.0f, ss = 0.0f;
         if (EPI != EPI_BIAS) { gg = g[col]; ss = sh[col]; }
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
+        for (int a = 0; a < TM; ++a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int lr = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const int lr = wm * 32 * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                 const long long row = m0 + lr;
                 float v = acc[a][b][r] + bb;
                 if (EPI == EPI_SOFTPLUS || EPI == EPI_SOFTPLUS_MUL) v = kLn2 * softplus_l2(fmaf(v, gg, ss));
@@ -152,6 +164,23 @@ __global__ __launch_bounds__(256, 2) void wide_gemm_kernel(const float* __restri
                 }
             }
         }
+    }
+}
+
+// One launch = n_main 128 x 128 tiles (rows [0, m_main), column block fastest) followed by 64 x 64 tiles over the rows
+// [m_main, M): the small tiles are dispatched last, into the workgroup slots the big ones free one by one.
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void wide_gemm_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                           const float* __restrict__ bias, const float* __restrict__ g,
+                                                           const float* __restrict__ sh, const float* __restrict__ mul,
+                                                           int mul_div, float* __restrict__ out, long long M, int K,
+                                                           int ldo, int cols, long long n_main, long long m_main) {
+    const long long id = blockIdx.x;
+    if (id < n_main) {
+        wide_gemm_tile<EPI, 128, 128>(A, W, bias, g, sh, mul, mul_div, out, m_main, K, ldo, 0, (int)(id % cols), id / cols);
+    } else {
+        const long long t = id - n_main;
+        wide_gemm_tile<EPI, 64, 64>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo, m_main, (int)(t % (2 * cols)), t / (2 * cols));
     }
 }
 
@@ -237,6 +266,165 @@ __global__ void wide_update_kernel(const float* __restrict__ eps, int ld_eps, co
     }
 }
 
+// Head + posterior update in ONE launch for up to 32 classes (every classification config but CIFAR-100; multi-output
+// regression): eps = h . W4^T + b4 (classification/model.py:94) followed by the update of wide_update_kernel.  As a GEMM
+// launch the head was a single, latency-bound round of N / 128 workgroups that each walked the whole K = F loop for a
+// 128-column tile of which C are real (0.31 ms of a 12.6 ms CIFAR-10 timestep, the update 5 us more); the work is a
+// read of h (N x F fp32, once) and C dot products per row, so it runs on the VALU at memory speed instead:
+//   * a wave owns RW rows at a time; lane l walks features 4l .. 4l+3 (+256 ...), one coalesced 1 KB row segment per
+//     load, and keeps RW x CP partial sums (fmaf in k order);
+//   * the 64 partial sums of every (row, class) are added by a halving butterfly: at the step with lane distance d the
+//     lane whose bit d is clear keeps the lower half of its values and hands the upper half to its partner (and vice
+//     versa), so the values per lane halve while the lane distance halves -- V + V/2 + ... shuffles for all V = RW x CP
+//     sums instead of 6 V, and value i ends on lane i / (V / 64).  The order of additions is the same for every value and
+//     fp32 addition commutes, so a row's eps does not depend on where the row sits in its group, the launch or the chunk;
+//   * that lane then updates its (row, class) elements: noise, coefficients and stores as in wide_update_kernel.
+struct HeadParams {
+    const float* h;          // (N, F) last hidden activations
+    const float* W4;         // (>= CP, F), rows >= C zero
+    const float* b4;
+    const float* mu;         // (rows, C)
+    const float* coef_row;
+    const float* noise_d;    // this draw's (N, C) block or NULL
+    float* S;                // (N, Kp) state matrix, columns [0, C) = y_t
+    float* out;
+    const int* state_slot;
+    float* eps_out;          // eps-only mode: (N, C), nothing else is touched
+    long long N, fixed_slot, slot_stride;
+    unsigned long long seed, elem_offset;
+    int F, C, Kp, n_z, draw, t, state;
+};
+
+template <int CP, int RW>
+__global__ __launch_bounds__(256) void wide_head_update_kernel(const HeadParams p) {
+    constexpr int V = CP * RW, PER = V / 64;
+    static_assert(V % 64 == 0 && (V & (V - 1)) == 0, "RW x CP must be a power of two >= 64");
+    // W4 is shared by every row: the four waves of a workgroup walk k in lockstep and read it through a double-buffered
+    // LDS slab of 256 features x C classes (one global read per workgroup instead of one per wave: with per-wave reads
+    // the kernel was bound by the 2.5 W4 loads it issued per row-segment load)
+    __shared__ __attribute__((aligned(16))) float slab[2][CP][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long groups = (p.N + RW - 1) / RW, sgroups = (groups + 3) / 4;
+    const int F = p.F, C = p.C;
+    float c_inv = 0.f, c_om = 0.f, c_s = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, sig = 0.f;
+    long long slot = -1;
+    if (!p.eps_out) {
+        c_inv = p.coef_row[CARD_COEF_INV_SQRT_AB]; c_om = p.coef_row[CARD_COEF_ONE_M_SQRT_AB]; c_s = p.coef_row[CARD_COEF_SOMAB];
+        g0 = p.coef_row[CARD_COEF_G0]; g1 = p.coef_row[CARD_COEF_G1]; g2 = p.coef_row[CARD_COEF_G2]; sig = p.coef_row[CARD_COEF_SIGMA];
+        slot = p.state_slot ? (long long)p.state_slot[p.state] : p.fixed_slot;
+    }
+    float* const out_slot = slot >= 0 ? p.out + slot * p.slot_stride : nullptr;
+    const int k0 = 4 * lane;
+    const int n_ks = (F + 255) / 256;
+    constexpr int WR = (CP + 3) / 4;                        // W4 rows a wave stages per slab: classes wv, wv + 4, ...
+    auto w_fetch = [&](int ks, f32x4 (&wr)[WR]) {
+#pragma unroll
+        for (int i = 0; i < WR; ++i) {
+            const int c = wv + 4 * i;
+            wr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < C && ks * 256 + k0 < F) wr[i] = *reinterpret_cast<const f32x4*>(p.W4 + (long long)c * F + ks * 256 + k0);
+        }
+    };
+    auto w_park = [&](int buf, const f32x4 (&wr)[WR]) {
+#pragma unroll
+        for (int i = 0; i < WR; ++i) {
+            const int c = wv + 4 * i;
+            if (c < CP) *reinterpret_cast<f32x4*>(&slab[buf][c][k0]) = wr[i];
+        }
+    };
+    for (long long sg = blockIdx.x; sg < sgroups; sg += gridDim.x) {     // uniform over the workgroup (barriers inside)
+        const long long grp = sg * 4 + wv;
+        float acc[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[i] = 0.0f;
+        const float* hrow[RW];
+#pragma unroll
+        for (int j = 0; j < RW; ++j) {
+            long long r = grp * RW + j;
+            r = r < p.N ? r : p.N - 1;
+            hrow[j] = p.h + r * F + k0;
+        }
+        // the row segments and the W4 slab of k-step i + 1 are requested before the FMAs of k-step i
+        f32x4 hv[RW], hn[RW], wr[WR];
+#pragma unroll
+        for (int j = 0; j < RW; ++j) hn[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (k0 < F) {
+#pragma unroll
+            for (int j = 0; j < RW; ++j) hn[j] = *reinterpret_cast<const f32x4*>(hrow[j]);
+        }
+        w_fetch(0, wr);
+        __syncthreads();                                   // the previous group's last slab has been read by every wave
+        w_park(0, wr);
+        __syncthreads();
+        for (int ks = 0; ks < n_ks; ++ks) {
+            const bool more = ks + 1 < n_ks;
+#pragma unroll
+            for (int j = 0; j < RW; ++j) hv[j] = hn[j];
+            if (more) {
+                w_fetch(ks + 1, wr);
+                if ((ks + 1) * 256 + k0 < F) {
+#pragma unroll
+                    for (int j = 0; j < RW; ++j) hn[j] = *reinterpret_cast<const f32x4*>(hrow[j] + (ks + 1) * 256);
+                }
+            }
+            if (ks * 256 + k0 < F) {
+#pragma unroll
+                for (int c = 0; c < CP; ++c) {
+                    if (c < C) {                           // uniform: padded classes cost nothing
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(&slab[ks & 1][c][k0]);
+#pragma unroll
+                        for (int j = 0; j < RW; ++j) {
+                            float a = acc[j * CP + c];
+                            a = fmaf(hv[j][0], w[0], a); a = fmaf(hv[j][1], w[1], a); a = fmaf(hv[j][2], w[2], a); a = fmaf(hv[j][3], w[3], a);
+                            acc[j * CP + c] = a;
+                        }
+                    }
+                }
+            }
+            if (more) w_park((ks + 1) & 1, wr);            // that buffer was last read at k-step ks - 1, before the barrier below of that trip
+            __syncthreads();
+        }
+        // halving butterfly: after the step with distance d a lane holds the values whose index bit (the one this step
+        // decides) equals its lane bit d
+#pragma unroll
+        for (int d = 32, half = V / 2; d >= 1; d >>= 1, half >>= 1) {
+            const bool up = (lane & d) != 0;
+#pragma unroll
+            for (int i = 0; i < half; ++i) {
+                const float keep = up ? acc[i + half] : acc[i];
+                const float send = up ? acc[i] : acc[i + half];
+                acc[i] = keep + __shfl_xor(send, d, 64);
+            }
+        }
+        // this lane's PER values: index i = PER * lane + s -> row i / CP of the group, class i % CP
+#pragma unroll
+        for (int s = 0; s < PER; ++s) {
+            const int i = PER * lane + s, j = i / CP, c = i % CP;
+            const long long n = grp * RW + j;
+            if (n >= p.N || c >= C) continue;
+            const float e = acc[s] + p.b4[c];
+            const long long el = n * C + c;
+            if (p.eps_out) { p.eps_out[el] = e; continue; }
+            const float m = p.mu[(n / p.n_z) * C + c], yy = p.S[n * p.Kp + c];
+            const float y0r = c_inv * ((yy - c_om * m) - e * c_s);
+            float v = y0r;
+            if (p.t >= 1) {
+                float z;
+                if (p.noise_d) {
+                    z = p.noise_d[el];
+                } else {
+                    float zz[4];
+                    philox_normal4(p.seed, p.elem_offset + (unsigned long long)el, (uint32_t)p.draw >> 2, zz);
+                    z = pick4(zz, p.draw & 3);
+                }
+                v = ((g0 * y0r + g1 * yy) + g2 * m) + sig * z;
+            }
+            p.S[n * p.Kp + c] = v;
+            if (out_slot) out_slot[el] = v;
+        }
+    }
+}
+
 __global__ void wide_copy_eps_kernel(const float* __restrict__ eps, int ld_eps, int C, long long n_elems,
                                      float* __restrict__ out) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_elems;
@@ -300,19 +488,32 @@ WideWs carve(void* base, long long N, int F, int Kp, int Cpad) {
     return w;
 }
 
+// out[M x Nout] = epilogue(A[M x K] . W[Nout x K]^T).  Whole rounds of 2 x num_cu resident 128 x 128 tiles, then, when the
+// last round would fill at most half of the chip, its rows as 64 x 64 tiles (see wide_gemm_tile) -- all in one launch.
 int gemm(int epi, const float* A, const float* W, const float* bias, const float* g, const float* sh, const float* mul,
-         int mul_div, float* out, long long M, int K, int Nout, int ldo, hipStream_t stream) {
-    dim3 grid((unsigned)(Nout / BN), (unsigned)((M + BM - 1) / BM));
+         int mul_div, float* out, long long M, int K, int Nout, int ldo, int num_cu, hipStream_t stream) {
+    const long long cols = Nout / BN, rb = (M + BM - 1) / BM, slots = 2LL * num_cu;
+    long long main_rb = rb;
+    static const bool tail_on = [] { const char* e = getenv("CARD_AMD_WIDE_TAIL"); return !(e && e[0] == '0'); }();   // A/B
+    if (tail_on && K >= 8 * BK && cols <= slots) {
+        const long long rb_round = slots / cols;                       // row blocks of one round of resident workgroups
+        const long long tail_rb = rb % rb_round;
+        if (tail_rb * cols * 2 <= slots) main_rb = rb - tail_rb;       // the last round is at most half full
+    }
+    const long long m_main = main_rb * BM < M ? main_rb * BM : M;
+    const long long n_main = main_rb * cols, n_tail = (M - m_main + 63) / 64 * (2 * cols);
+    const dim3 grid((unsigned)(n_main + n_tail));
+    const int c = (int)cols;
     if (epi == EPI_SOFTPLUS)
-        wide_gemm_kernel<EPI_SOFTPLUS><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo);
+        wide_gemm_kernel<EPI_SOFTPLUS><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo, c, n_main, m_main);
     else if (epi == EPI_SOFTPLUS_MUL)
-        wide_gemm_kernel<EPI_SOFTPLUS_MUL><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo);
+        wide_gemm_kernel<EPI_SOFTPLUS_MUL><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo, c, n_main, m_main);
     else if (epi == EPI_SCALE)
-        wide_gemm_kernel<EPI_SCALE><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo);
+        wide_gemm_kernel<EPI_SCALE><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo, c, n_main, m_main);
     else if (epi == EPI_SCALE_MUL)
-        wide_gemm_kernel<EPI_SCALE_MUL><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo);
+        wide_gemm_kernel<EPI_SCALE_MUL><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo, c, n_main, m_main);
     else
-        wide_gemm_kernel<EPI_BIAS><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo);
+        wide_gemm_kernel<EPI_BIAS><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo, c, n_main, m_main);
     HIP_TRY(hipGetLastError());
     return CARD_OK;
 }
@@ -355,11 +556,12 @@ int wide_create(card_sampler* s, const card_model_desc* d, hipStream_t stream) {
     HIP_TRY(hipMalloc(&s->bias, (size_t)(3 * F + Cpad) * 4));
     HIP_TRY(hipMalloc(&s->shift, (size_t)3 * F * 4));
     HIP_TRY(hipMalloc(&s->gtab, (size_t)d->n_embed * 3 * F * 4));
-    HIP_TRY(hipFuncSetAttribute((const void*)wide_gemm_kernel<EPI_SOFTPLUS>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
-    HIP_TRY(hipFuncSetAttribute((const void*)wide_gemm_kernel<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
-    HIP_TRY(hipFuncSetAttribute((const void*)wide_gemm_kernel<EPI_SOFTPLUS_MUL>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
-    HIP_TRY(hipFuncSetAttribute((const void*)wide_gemm_kernel<EPI_SCALE>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
-    HIP_TRY(hipFuncSetAttribute((const void*)wide_gemm_kernel<EPI_SCALE_MUL>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
+    {
+        const void* fns[] = {(const void*)wide_gemm_kernel<EPI_SOFTPLUS>, (const void*)wide_gemm_kernel<EPI_BIAS>,
+                             (const void*)wide_gemm_kernel<EPI_SOFTPLUS_MUL>, (const void*)wide_gemm_kernel<EPI_SCALE>,
+                             (const void*)wide_gemm_kernel<EPI_SCALE_MUL>};
+        for (const void* fn : fns) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
+    }
     wide_pad_cols_kernel<<<grid_for((long long)F * Kp), 256, 0, stream>>>(d->W[0], F, d1, Kp, s->W1);
     HIP_TRY(hipMemcpyAsync(s->W2, d->W[1], FF * 4, hipMemcpyDeviceToDevice, stream));
     if (!linear) HIP_TRY(hipMemcpyAsync(s->W3, d->W[2], FF * 4, hipMemcpyDeviceToDevice, stream));
@@ -401,28 +603,58 @@ int wide_run_chunk(const card_sampler* s, const CardRun& r, long long stride, hi
     const float* b4 = s->bias + 3 * (size_t)F;
     const bool guided = s->variant == CARD_VARIANT_GUIDED;
 
-    // one eps_theta forward from the state matrix S (y_t | y_0_hat | [x] | 0) at timestep t -> w.eps (N x Cpad)
-    auto forward = [&](int t) -> int {
+    // the hidden layers of one eps_theta forward from the state matrix S (y_t | y_0_hat | [x] | 0) at timestep t; *last =
+    // the buffer that holds the activations lin4 reads
+    auto hidden = [&](int t, const float** last) -> int {
         const float* g = s->gtab + (size_t)t * 3 * F;
         int rc;
         if (s->variant == CARD_VARIANT_LINEAR_HADAMARD) {
             // lin3( gamma2 * lin2( linx(z) * (gamma1 * lin1(S)) ) ), imagenet/card/builder.py:86-92
-            if ((rc = gemm(EPI_SCALE_MUL, w.S, s->W1, b1, g, s->shift, r.x, r.n_z, w.hA, N, Kp, F, F, stream))) return rc;
-            if ((rc = gemm(EPI_SCALE, w.hA, s->W2, b2, g + F, s->shift + F, nullptr, 1, w.hB, N, F, F, F, stream))) return rc;
-            return gemm(EPI_BIAS, w.hB, s->W4, b4, nullptr, nullptr, nullptr, 1, w.eps, N, F, Cpad, Cpad, stream);
+            if ((rc = gemm(EPI_SCALE_MUL, w.S, s->W1, b1, g, s->shift, r.x, r.n_z, w.hA, N, Kp, F, F, s->num_cu, stream))) return rc;
+            *last = w.hB;
+            return gemm(EPI_SCALE, w.hA, s->W2, b2, g + F, s->shift + F, nullptr, 1, w.hB, N, F, F, F, s->num_cu, stream);
         }
-        if ((rc = gemm(guided ? EPI_SOFTPLUS : EPI_SOFTPLUS_MUL, w.S, s->W1, b1, g, s->shift, r.x, r.n_z, w.hA, N, Kp, F, F, stream))) return rc;
-        if ((rc = gemm(EPI_SOFTPLUS, w.hA, s->W2, b2, g + F, s->shift + F, nullptr, 1, w.hB, N, F, F, F, stream))) return rc;
-        if ((rc = gemm(EPI_SOFTPLUS, w.hB, s->W3, b3, g + 2 * (size_t)F, s->shift + 2 * (size_t)F, nullptr, 1, w.hA, N, F, F, F, stream))) return rc;
-        return gemm(EPI_BIAS, w.hA, s->W4, b4, nullptr, nullptr, nullptr, 1, w.eps, N, F, Cpad, Cpad, stream);
+        if ((rc = gemm(guided ? EPI_SOFTPLUS : EPI_SOFTPLUS_MUL, w.S, s->W1, b1, g, s->shift, r.x, r.n_z, w.hA, N, Kp, F, F, s->num_cu, stream))) return rc;
+        if ((rc = gemm(EPI_SOFTPLUS, w.hA, s->W2, b2, g + F, s->shift + F, nullptr, 1, w.hB, N, F, F, F, s->num_cu, stream))) return rc;
+        *last = w.hA;
+        return gemm(EPI_SOFTPLUS, w.hB, s->W3, b3, g + 2 * (size_t)F, s->shift + 2 * (size_t)F, nullptr, 1, w.hA, N, F, F, F, s->num_cu, stream);
     };
+    // lin4 as a GEMM launch into w.eps (N x Cpad): more than kHeadFusedMaxC classes, or CARD_AMD_WIDE_HEAD=gemm (A/B)
+    auto head_gemm = [&](const float* last) -> int {
+        return gemm(EPI_BIAS, last, s->W4, b4, nullptr, nullptr, nullptr, 1, w.eps, N, F, Cpad, Cpad, s->num_cu, stream);
+    };
+    const char* hv = getenv("CARD_AMD_WIDE_HEAD");
+    const bool fused_head = C <= kHeadFusedMaxC && !(hv && hv[0] == 'g');
+    // lin4 + posterior update (or eps only) in one VALU launch
+    auto head_fused = [&](const HeadParams& hp) -> int {
+        // a wave owns RW = 64 / CP rows at a time; as many waves as give every wave the same number of row groups
+        const int RW = C <= 8 ? 8 : (C <= 16 ? 4 : 2);
+        const long long sgroups = ((N + RW - 1) / RW + 3) / 4, max_wgs = (long long)s->num_cu * 2;   // resident workgroups (registers)
+        const long long rounds = (sgroups + max_wgs - 1) / max_wgs;
+        const dim3 grid((unsigned)((sgroups + rounds - 1) / rounds));
+        if (C <= 8) wide_head_update_kernel<8, 8><<<grid, 256, 0, stream>>>(hp);
+        else if (C <= 16) wide_head_update_kernel<16, 4><<<grid, 256, 0, stream>>>(hp);
+        else wide_head_update_kernel<32, 2><<<grid, 256, 0, stream>>>(hp);
+        HIP_TRY(hipGetLastError());
+        return CARD_OK;
+    };
+    HeadParams hp;
+    memset(&hp, 0, sizeof(hp));
+    hp.W4 = s->W4; hp.b4 = b4; hp.mu = r.ytmean; hp.S = w.S; hp.out = r.out; hp.N = N; hp.slot_stride = stride;
+    hp.seed = r.seed; hp.elem_offset = r.elem_offset; hp.F = F; hp.C = C; hp.Kp = Kp; hp.n_z = r.n_z;
     // static columns of S (+ y_t when the caller supplies it)
     wide_pack_state_kernel<<<grid_for(N * Kp), 256, 0, stream>>>(r.y_init, r.y0hat, guided ? r.x : nullptr, C, s->cat_y_pred,
                                                                 (guided && s->cat_x) ? s->x_dim : 0, Kp, r.n_z, N, w.S);
     HIP_TRY(hipGetLastError());
 
     if (r.eps_only) {
-        if (int rc = forward(r.t_hi)) return rc;
+        const float* last = nullptr;
+        if (int rc = hidden(r.t_hi, &last)) return rc;
+        if (fused_head) {
+            hp.h = last; hp.eps_out = r.out;
+            return head_fused(hp);
+        }
+        if (int rc = head_gemm(last)) return rc;
         wide_copy_eps_kernel<<<grid_for(ne), 256, 0, stream>>>(w.eps, Cpad, C, ne, r.out);
         HIP_TRY(hipGetLastError());
         return CARD_OK;
@@ -438,9 +670,17 @@ int wide_run_chunk(const card_sampler* s, const CardRun& r, long long stride, hi
         HIP_TRY(hipGetLastError());
     }
     for (int t = r.t_hi; t >= r.t_lo; --t) {
-        if (int rc = forward(t)) return rc;
+        const float* last = nullptr;
+        if (int rc = hidden(t, &last)) return rc;
         const int draw = T - t;
         const float* nz = (r.noise && t >= 1) ? r.noise + (long long)(draw - base) * stride : nullptr;
+        if (fused_head) {
+            hp.h = last; hp.coef_row = r.coef + (size_t)t * CARD_COEF_COLS; hp.noise_d = nz; hp.draw = draw; hp.t = t;
+            hp.state_slot = sel; hp.state = T - t; hp.fixed_slot = fixed(T - t);
+            if (int rc = head_fused(hp)) return rc;
+            continue;
+        }
+        if (int rc = head_gemm(last)) return rc;
         wide_update_kernel<<<grid_for(ne), 256, 0, stream>>>(w.eps, Cpad, r.ytmean, r.coef + (size_t)t * CARD_COEF_COLS, nz,
                                                             r.seed, r.elem_offset, draw, t, C, ne, Kp, r.n_z, w.S, r.out, sel, T - t,
                                                             fixed(T - t), stride);
