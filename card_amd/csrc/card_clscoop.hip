@@ -30,7 +30,8 @@ constexpr int kExLd = kF + 4;      // activation exchange row stride (floats)
 constexpr int kYLd = kCmax + 4;    // ys / partial-tile row stride
 constexpr int kGRow = 3 * kF;
 constexpr int kTab = 6 * kF + kCmax;                 // b1|b2|b3 | shift1|shift2|shift3 (log2 units) | b4
-constexpr int kTileLdsFloats = 2 * kTileM * kExLd + kTileM * kYLd + kWaves * kTileM * kYLd + 2 * kGRow;   // per tile position
+constexpr int kZFloats = 4 * kTileM * kYLd;          // normals of a tile's current draw block: [draw & 3][chain][class]
+constexpr int kTileLdsFloats = 2 * kTileM * kExLd + kTileM * kYLd + kWaves * kTileM * kYLd + 2 * kGRow + kZFloats;   // per tile position
 constexpr int kGmax = 2;                             // tile positions per workgroup
 constexpr long long kChunkTiles = 8192;              // tiles per sliced chunk: bounds the hand-over buffer (262 144 chains)
 __host__ __device__ constexpr int lds_floats(int G) { return G * kTileLdsFloats + kTab; }
@@ -63,6 +64,13 @@ struct ClsCoopParams {
     int n_seg, g_eff;
     float* ybuf;          // (n_end - n_begin, C) chain states between the segments of a tile
 };
+
+#ifdef CARD_CLS_PROFILE
+__device__ long long g_cls_prof[64];
+#define PROF_T(i) do { pts[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PROF_T(i) do { } while (0)
+#endif
 
 namespace {
 
@@ -106,7 +114,7 @@ __device__ __forceinline__ void epilogue_bn(f32x16& acc, const float* gl, const 
 template <int G>
 __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const ClsCoopParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int kTileLds = 2 * kTileM * kExLd + kTileM * kYLd + kWaves * kTileM * kYLd + 2 * kGRow;
+    constexpr int kTileLds = kTileLdsFloats;
     float* const tab = lds + G * kTileLds;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -146,13 +154,13 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
     const int n_steps = p.t_hi - p.t_lo + 1;
 
     // ---- the G tile positions of this workgroup
-    float* ex[G]; float* ys[G]; float* red[G]; float* gsl[G];
+    float* ex[G]; float* ys[G]; float* red[G]; float* gsl[G]; float* zbuf[G];
     float* exw[G]; const float* exr[G]; float* ysw[G]; const float* ysr[G];
     bool active[G], valid[G], first_seg[G], last_seg[G];
     long long row[G], rc[G], rr[G];
     int th[G], cnt[G], gcur[G];
     f32x16 c1[G], xf[G];
-    float yv[G][4], mu[G][4], zc[G][4][4];
+    float yv[G][4], mu[G][4];
     uint32_t zblock[G];
     int n_iter = 0;
 #pragma unroll
@@ -162,6 +170,7 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
         ys[g] = ex[g] + 2 * kTileM * kExLd;                  // [32][36] y_t, chain-major
         red[g] = ys[g] + kTileM * kYLd;                      // [4][32][36] lin4 partial tiles
         gsl[g] = red[g] + kWaves * kTileM * kYLd;            // 2 gamma rows
+        zbuf[g] = gsl[g] + 2 * kGRow;                        // [4][32][36] normals of the current draw block
         exw[g] = ex[g] + m * kExLd + 32 * w + 4 * hh;
         exr[g] = ex[g] + m * kExLd + 4 * hh;
         ysw[g] = ys[g] + m * kYLd + c0;
@@ -186,21 +195,27 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
     // every wave of the workgroup must walk the same number of barrier rounds
     n_iter = __builtin_amdgcn_readfirstlane(n_iter);
 
-    auto draw = [&](int g, int d, float (&z)[4]) {
-        if (p.noise) {
+    // Noise.  One Philox call yields the four normals of four consecutive draws of ONE (chain, class) element, so a
+    // tile needs 32 C calls per four timesteps.  They are spread over all 256 lanes of the workgroup (element e = chain * C
+    // + class on thread e mod 256: 1.25 calls per lane at C = 10) and parked in LDS as [draw & 3][chain][class]; the lane
+    // that updates classes c0 .. c0+3 of a chain reads its four normals of a draw with one ds_read_b128.  (Every lane
+    // drawing for its own four classes cost 4 calls per lane whatever C: 1 400 cycles per timestep on every wave.)
+    const float inv_c = 1.0f / (float)C;
+    auto gen_block = [&](int g, uint32_t blk) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) z[k] = c0 + k < C ? p.noise[(long long)(d - draw0) * NC + rc[g] * C + c0 + k] : 0.0f;
-            return;
+        for (int j = 0; j < 4; ++j) {
+            const int e = tid + kThreads * j;
+            if (e < kTileM * C) {
+                const int chain = (int)(((float)e + 0.5f) * inv_c), cls = e - chain * C;       // exact for e < 1024
+                long long re = row[g] - m + chain;
+                re = re < p.n_end ? re : p.n_end - 1;
+                float z4[4];
+                philox_normal4(p.seed, p.elem_offset + (unsigned long long)(re * C + cls), blk, z4);
+                float* zb = zbuf[g] + chain * kYLd + cls;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) zb[k * kTileM * kYLd] = z4[k];
+            }
         }
-        const uint32_t blk = (uint32_t)d >> 2;
-        if (blk != zblock[g]) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                philox_normal4(p.seed, p.elem_offset + (unsigned long long)(rc[g] * C + (c0 + k < C ? c0 + k : 0)), blk, zc[g][k]);
-            zblock[g] = blk;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) z[k] = pick4(zc[g][k], d & 3);
     };
     auto store_state = [&](int g, int s) {
         long long slot;
@@ -214,6 +229,11 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
     };
 
     // ---- per-tile prologue: hoisted static part of layer 1, this wave's x_feat block, the chain state
+    const bool rng = !p.noise && !p.eps_only;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+        if (active[g] && first_seg[g] && !p.y_init && rng) { gen_block(g, 0u); zblock[g] = 0u; }     // draw 0 makes y_T
+    __syncthreads();
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         if (!active[g]) continue;
@@ -245,8 +265,13 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
 #pragma unroll
             for (int k = 0; k < 4; ++k) yv[g][k] = c0 + k < C ? p.y_init[rc[g] * C + c0 + k] : 0.0f;
         } else {
-            float z[4];
-            draw(g, 0, z);
+            f32x4 z;
+            if (p.noise) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) z[k] = c0 + k < C ? p.noise[rc[g] * C + c0 + k] : 0.0f;
+            } else {
+                z = lds4(zbuf[g] + m * kYLd + c0);
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) yv[g][k] = c0 + k < C ? z[k] + mu[g][k] : 0.0f;       // classification/diffusion_utils.py:123-124
             store_state(g, 0);
@@ -279,9 +304,13 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
     };
 
     for (int it = 0; it < n_iter; ++it) {
+#ifdef CARD_CLS_PROFILE
+        long long pts[9];
+#endif
+        PROF_T(0);
         bool on[G], more[G];
         f32x4 gn[G];
-        float z[G][4];
+        float z[G][4], cf[G][7] = {};
         const float* gl[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -294,7 +323,22 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
             if (!on[g]) continue;
             const int t = th[g] - it;
             if (more[g] && tid < kGRow / 4) gn[g] = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(t - 1) * kGRow + tid * 4);
-            if (t >= 1 && !p.eps_only) draw(g, T - t, z[g]);
+            // this timestep's coefficient row (scalar loads, issued a whole timestep ahead of their use)
+            if (!p.eps_only) {                             // (card_eps_theta passes no table)
+                const float* c = p.coef + (long long)t * CARD_COEF_COLS;
+                cf[g][0] = c[CARD_COEF_INV_SQRT_AB]; cf[g][1] = c[CARD_COEF_ONE_M_SQRT_AB]; cf[g][2] = c[CARD_COEF_SOMAB];
+                cf[g][3] = c[CARD_COEF_G0]; cf[g][4] = c[CARD_COEF_G1]; cf[g][5] = c[CARD_COEF_G2]; cf[g][6] = c[CARD_COEF_SIGMA];
+            }
+            if (t >= 1 && !p.eps_only) {
+                const int d = T - t;
+                if (p.noise) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) z[g][k] = c0 + k < C ? p.noise[(long long)(d - draw0) * NC + rc[g] * C + c0 + k] : 0.0f;
+                } else if (((uint32_t)d >> 2) != zblock[g]) {
+                    zblock[g] = (uint32_t)d >> 2;
+                    gen_block(g, zblock[g]);              // read after the third barrier of this timestep
+                }
+            }
             // layer 1 (model.py:82-87): c1 + W1[:, 0:C] . y_t, BN, softplus, Hadamard with x_feat
             f32x16 acc = c1[g];
 #pragma unroll
@@ -310,14 +354,18 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
             for (int r = 0; r < 16; ++r) acc[r] *= xf[g][r];
             publish(g, acc, 0);
         }
+        PROF_T(1);
         __syncthreads();
+        PROF_T(2);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             if (!on[g]) continue;
             const f32x16 acc = hidden(g, A2, 0, 1, gl[g]);
             publish(g, acc, 1);
         }
+        PROF_T(3);
         __syncthreads();
+        PROF_T(4);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             if (!on[g]) continue;
@@ -334,7 +382,9 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
                 *reinterpret_cast<f32x4*>(red[g] + (w * kTileM + m) * kYLd + 8 * q + 4 * hh) =
                     f32x4{part[4 * q + 0], part[4 * q + 1], part[4 * q + 2], part[4 * q + 3]};
         }
+        PROF_T(5);
         __syncthreads();
+        PROF_T(6);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             if (!on[g]) continue;
@@ -354,9 +404,12 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
                 continue;
             }
             // posterior update per (chain, class), classification/diffusion_utils.py:80-86 (t >= 1) / :98-100 (t == 0)
-            const float* c = p.coef + (long long)t * CARD_COEF_COLS;
-            const float ci = c[CARD_COEF_INV_SQRT_AB], co = c[CARD_COEF_ONE_M_SQRT_AB], cs = c[CARD_COEF_SOMAB];
-            const float g0 = c[CARD_COEF_G0], g1 = c[CARD_COEF_G1], g2 = c[CARD_COEF_G2], sg = c[CARD_COEF_SIGMA];
+            const float ci = cf[g][0], co = cf[g][1], cs = cf[g][2], g0 = cf[g][3], g1 = cf[g][4], g2 = cf[g][5], sg = cf[g][6];
+            if (t >= 1 && !p.noise) {
+                const f32x4 zz = lds4(zbuf[g] + ((T - t) & 3) * kTileM * kYLd + m * kYLd + c0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) z[g][k] = zz[k];
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float y0r = ci * ((yv[g][k] - co * mu[g][k]) - eps[k] * cs);
@@ -367,7 +420,13 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
             store_state(g, T - t);
             *reinterpret_cast<f32x4*>(ysw[g]) = f32x4{yv[g][0], yv[g][1], yv[g][2], yv[g][3]};
         }
+        PROF_T(7);
         __syncthreads();
+        PROF_T(8);
+#ifdef CARD_CLS_PROFILE
+        if (blockIdx.x == 0 && lane == 0)
+            for (int i = 0; i < 8; ++i) g_cls_prof[w * 8 + i] += pts[i + 1] - pts[i];
+#endif
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -536,3 +595,12 @@ int clscoop_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     }
     return CARD_OK;
 }
+
+#ifdef CARD_CLS_PROFILE
+// profile build only (tools/prof_cls_phases.sh): cycles per phase of workgroup 0, [wave][phase]
+extern "C" CARD_API int card_debug_cls_prof(long long* host64, int reset) {
+    if (host64) HIP_TRY(hipMemcpyFromSymbol(host64, HIP_SYMBOL(g_cls_prof), sizeof(long long) * 64));
+    if (reset) { long long z[64] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_cls_prof), z, sizeof(z))); }
+    return CARD_OK;
+}
+#endif
