@@ -26,17 +26,28 @@ namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 4;
 constexpr int kStageFloats = (BM + BN) * LDT;
-constexpr int kGemmLds = 2 * kStageFloats * (int)sizeof(float);   // 73 728 B -> two blocks per CU
+// One LDS stage (36 KB: the next k tile waits in registers while this one is computed, two barriers per tile) and four
+// workgroups per CU beat round 1's two stages / two workgroups per CU: four waves per SIMD keep the matrix pipe fed through
+// each other's barriers (CIFAR-10 minibatch 12.24 -> 11.73 ms per timestep; three per CU 11.85).  128 VGPRs: the compiler
+// spills 14 registers, all of them in the epilogue.  -DCARD_WIDE_2STAGE / -DCARD_WIDE_WG3 build the other forms (A/B).
+#if defined(CARD_WIDE_2STAGE)
+constexpr int kGemmStages = 2, kGemmWgPerCu = 2;
+#elif defined(CARD_WIDE_WG3)
+constexpr int kGemmStages = 1, kGemmWgPerCu = 3;
+#else
+constexpr int kGemmStages = 1, kGemmWgPerCu = 4;
+#endif
+constexpr int kGemmLds = kGemmStages * kStageFloats * (int)sizeof(float);   // 36 864 B per stage
 
 constexpr int kHeadFusedMaxC = 32;     // wide_head_update_kernel
 enum { EPI_SOFTPLUS = 0, EPI_BIAS = 1, EPI_SOFTPLUS_MUL = 2, EPI_SCALE = 3, EPI_SCALE_MUL = 4 };
 
 // TBM = TBN = 128: the 128 x 128 block tile (4 waves as 2 x 2, each 2 x 2 MFMA tiles).  TBM = TBN = 64: 64 x 64 (each wave one
-// tile, two workgroups per CU), same k loop, for the last, partly filled round of a launch: the reference's test minibatch of 250 images x 100 z
-// is 196 row blocks x 32 column blocks = 12.25 rounds of 512 resident workgroups, and the 128 tiles of the last quarter
-// round used to cost 0.57 of a full round (each alone on a CU: one wave per SIMD hides neither the barrier nor the load latency); as four times as many 64 x 64
-// tiles, two per CU, they cost about half that.  Every output
-// element is the same fp32 FMA chain over k in either shape, so which shape computes a row changes no bits.
+// tile), same k loop, for the last, partly filled round of a launch: the reference's test minibatch of 250 images x 100 z
+// is 196 row blocks x 32 column blocks = 6.125 rounds of the 1 024 resident workgroups, and 128 big tiles on an otherwise
+// empty chip (one per CU: a single wave per SIMD hides neither the barriers nor the load latency) cost more than half a full
+// round; as four times as many 64 x 64 tiles they cost about half that.  Every output element is the same fp32 FMA chain
+// over k in either shape, so which shape computes a row changes no bits.
 template <int EPI, int TBM, int TBN>
 __device__ __forceinline__ void wide_gemm_tile(const float* __restrict__ A, const float* __restrict__ W,
                                                const float* __restrict__ bias, const float* __restrict__ g,
@@ -115,6 +126,16 @@ __device__ __forceinline__ void wide_gemm_tile(const float* __restrict__ A, cons
     g_load(0);
     s_store(0);
     __syncthreads();
+#ifndef CARD_WIDE_2STAGE
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) g_load(kt + 1);
+        compute(0);
+        __syncthreads();
+        if (more) s_store(0);
+        __syncthreads();
+    }
+#else
     int kt = 0;
     for (; kt + 2 <= nk; kt += 2) {                        // two k tiles per trip: stage 0 then stage 1
         const bool more = kt + 2 < nk;
@@ -131,6 +152,7 @@ __device__ __forceinline__ void wide_gemm_tile(const float* __restrict__ A, cons
         compute(0);
         __syncthreads();
     }
+#endif
     // Hadamard operand row of each chain row of this block (chain / n_z), one 64-bit division per row instead of
     // one per element: table in LDS (the tiles are dead after the loop's last barrier)
     int* mrow = reinterpret_cast<int*>(sm);
@@ -170,7 +192,7 @@ __device__ __forceinline__ void wide_gemm_tile(const float* __restrict__ A, cons
 // One launch = n_main 128 x 128 tiles (rows [0, m_main), column block fastest) followed by 64 x 64 tiles over the rows
 // [m_main, M): the small tiles are dispatched last, into the workgroup slots the big ones free one by one.
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void wide_gemm_kernel(const float* __restrict__ A, const float* __restrict__ W,
+__global__ __launch_bounds__(256, kGemmWgPerCu) void wide_gemm_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                            const float* __restrict__ bias, const float* __restrict__ g,
                                                            const float* __restrict__ sh, const float* __restrict__ mul,
                                                            int mul_div, float* __restrict__ out, long long M, int K,
@@ -488,11 +510,11 @@ WideWs carve(void* base, long long N, int F, int Kp, int Cpad) {
     return w;
 }
 
-// out[M x Nout] = epilogue(A[M x K] . W[Nout x K]^T).  Whole rounds of 2 x num_cu resident 128 x 128 tiles, then, when the
+// out[M x Nout] = epilogue(A[M x K] . W[Nout x K]^T).  Whole rounds of kGemmWgPerCu x num_cu resident 128 x 128 tiles, then, when the
 // last round would fill at most half of the chip, its rows as 64 x 64 tiles (see wide_gemm_tile) -- all in one launch.
 int gemm(int epi, const float* A, const float* W, const float* bias, const float* g, const float* sh, const float* mul,
          int mul_div, float* out, long long M, int K, int Nout, int ldo, int num_cu, hipStream_t stream) {
-    const long long cols = Nout / BN, rb = (M + BM - 1) / BM, slots = 2LL * num_cu;
+    const long long cols = Nout / BN, rb = (M + BM - 1) / BM, slots = (long long)kGemmWgPerCu * num_cu;
     long long main_rb = rb;
     static const bool tail_on = [] { const char* e = getenv("CARD_AMD_WIDE_TAIL"); return !(e && e[0] == '0'); }();   // A/B
     if (tail_on && K >= 8 * BK && cols <= slots) {
