@@ -516,7 +516,8 @@ int gemm(int epi, const float* A, const float* W, const float* bias, const float
          int mul_div, float* out, long long M, int K, int Nout, int ldo, int num_cu, hipStream_t stream) {
     const long long cols = Nout / BN, rb = (M + BM - 1) / BM, slots = (long long)kGemmWgPerCu * num_cu;
     long long main_rb = rb;
-    static const bool tail_on = [] { const char* e = getenv("CARD_AMD_WIDE_TAIL"); return !(e && e[0] == '0'); }();   // A/B
+    const char* te = getenv("CARD_AMD_WIDE_TAIL");                  // A/B and tests: 0 = 128 x 128 tiles only
+    const bool tail_on = !(te && te[0] == '0');
     if (tail_on && K >= 8 * BK && cols <= slots) {
         const long long rb_round = slots / cols;                       // row blocks of one round of resident workgroups
         const long long tail_rb = rb % rb_round;
