@@ -231,12 +231,13 @@ def main():
             launches = (1 if tiles <= cu else math.ceil(tiles * n_seg / per)) * a.steps
             kernel = "card_sample_cls_coop_kernel"
         else:
-            # GEMM back end: a timestep is 4 GEMM launches + 1 update launch per chunk of chains; the two F x F
+            # GEMM back end: a timestep is 3 GEMM launches (layer 1 over the padded state matrix, two F x F) + one VALU launch
+            # (lin4 + posterior update; a 4th GEMM + an update launch above 32 classes) per chunk of chains; the two F x F
             # wide_gemm_kernel<EPI_SOFTPLUS> launches carry > 95 % of the flops.  `achieved` below still divides the
             # algorithmic flops by the WHOLE timed region (every launch), so it is a lower bound for that kernel.
             chunk = None
             launches = 2 * T * a.steps
-            kernel = "wide_gemm_kernel<EPI_SOFTPLUS> (+ layer-1 / head GEMM and update launches, all inside the timed region)"
+            kernel = "wide_gemm_kernel<EPI_SOFTPLUS> (+ layer-1 GEMM and head/update launches, all inside the timed region)"
         avg_launch_ms = ev_ms / launches
         achieved = (float(N) * T * a.steps * flops_per_unit) / (ev_ms * 1e-3) / 1e12
         # flops the kernels actually issue per sample-step (`achieved` prices the ALGORITHMIC count of SURVEY.md 8d, which
@@ -250,7 +251,8 @@ def main():
         elif cls_coop:
             executed = 2 * H * (8 * ((y_dim + 7) // 8) + 2 * H + 32)                  # card_clscoop.hip: y_t columns in 8s, lin4 as a 32-class MFMA tile
         else:
-            executed = 2 * H * (32 * ((d_in + 31) // 32) + 2 * H + 128 * ((y_dim + 127) // 128))   # card_wide.hip: K and head padded
+            head = y_dim if y_dim <= 32 else 128 * ((y_dim + 127) // 128)                      # fused VALU head, or a GEMM padded to 128 columns
+            executed = 2 * H * (32 * ((d_in + 31) // 32) + 2 * H + head)                        # card_wide.hip: layer-1 K padded to 32s
         achieved_exec = achieved * executed / flops_per_unit
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
