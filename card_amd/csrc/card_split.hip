@@ -33,6 +33,13 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef CARD_SPLIT_PROFILE
+__device__ long long g_split_prof[8 * 8];
+#define SPT(i) do { pts[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SPT(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int kH = 128;
@@ -85,6 +92,7 @@ namespace {
 
 // gamma multiply + softplus (log2 units) of a 32 x 32 block, in place
 __device__ __forceinline__ void softplus_block(f32x16& a, const float (&g)[16]) {
+    __builtin_amdgcn_s_setprio(3);           // VALU stretches go first: the other wave of the SIMD is (ideally) in its MFMAs
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] = softplus_l2(a[r] * g[r]);
 }
@@ -104,6 +112,7 @@ __device__ __forceinline__ void publish_split(const f32x16& a, char* dst /* tile
         *reinterpret_cast<u32x4*>(dst + kPartBytes + c * 1024) = m[c];
         *reinterpret_cast<u32x4*>(dst + 2 * kPartBytes + c * 1024) = l[c];
     }
+    __builtin_amdgcn_s_setprio(0);
 }
 
 // one 128 -> 32 (this wave's rows) layer of a tile: 8 k-steps x 6 bf16 MFMAs into three accumulators
@@ -151,11 +160,14 @@ __device__ __forceinline__ f32x16 layer_split(const bf16x8 (&W)[3][8], const cha
 
 // ------------------------------------------------------------------------------------------------
 // The kernel.  Eight waves per workgroup, two per SIMD, one workgroup per CU:
-//   waves 0-3 ("front"):  hold the A fragments of W2.  Per interval: layer 2 of one tile
-//   waves 4-7 ("back"):   hold the A fragments of W3 and the chains' states.  Per interval: the posterior update of a
-//                         second tile from the eps that its lin4 partial sums give and layer 1 of its next timestep (VALU
-//                         only), then layer 3 + this wave's lin4 partial sums of a third tile, the noise of its coming
-//                         draws and the gamma / coefficient rows of its next timestep
+//   waves 0-3 ("front"):  hold the A fragments of W2 and the chains' states.  Per interval: the posterior update of one
+//                         tile from the eps that its lin4 partial sums give and layer 1 of its next timestep (VALU
+//                         only), then layer 2 of a second tile
+//   waves 4-7 ("back"):   hold the A fragments of W3.  Per interval: layer 3 + this wave's lin4 partial sums of a third
+//                         tile, the noise of its coming draws and the gamma / coefficient rows of its next timestep
+// (the update + layer-1 stage sat on the back waves at first: cycle counters around the stages -- tools/prof_split_phases.py
+// on a -DCARD_SPLIT_PROFILE build -- showed them working 7 900 cycles per interval slot while the front waves worked 3 100
+// and waited 5 000; moved over, the slot is 6 000 / 4 400 cycles of work and the kernel 8 % faster)
 // Three tiles (32 chains each) rotate through the three stages, one workgroup barrier per interval, so every interval
 // advances every tile by a third of a timestep and a timestep costs three intervals whatever the stage.  The two waves
 // of a SIMD are independent instruction streams: while one sits in its 48 MFMAs the other issues its gamma / softplus /
@@ -294,12 +306,12 @@ __global__ __launch_bounds__(kThreads8) void card_sample_split_kernel(const Spli
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     *reinterpret_cast<f32x4*>(c1w + g * kC1Floats + q * 256) = f32x4{c1[g][4 * q], c1[g][4 * q + 1], c1[g][4 * q + 2], c1[g][4 * q + 3]};
+#pragma unroll
+            for (int g = 0; g < kSets; ++g) mu[g] = p.ytmean[rr[g]];
         } else {
             const f32x4 r0 = row_fetch(p.t_hi);
 #pragma unroll
             for (int g = 0; g < kSets; ++g) {
-                const long long rc = p.n_begin + rci0(g);
-                mu[g] = p.ytmean[p.n_z > 1 ? rc / p.n_z : rc];
                 row_park(g, 0, r0);
                 if (rng && !p.y_init) gen_block(g, 0u);                       // draw 0 makes y_T
             }
@@ -326,7 +338,7 @@ __global__ __launch_bounds__(kThreads8) void card_sample_split_kernel(const Spli
             float* const ob = p.out + slot * p.N + p.n_begin;                 // scalar base + 32-bit lane offset: no 64-bit lane addresses
             if (slot >= 0 && rowi(g) < n_here && li.hh == 0 && w == 0) ob[rowi(g)] = v;
         };
-        if (back) {
+        if (!back) {
 #pragma unroll
             for (int g = 0; g < kSets; ++g) {
                 if (p.y_init) {
@@ -341,7 +353,7 @@ __global__ __launch_bounds__(kThreads8) void card_sample_split_kernel(const Spli
 
         // ---- the three stages of a tile's timestep; i = index of the timestep in this call (t = t_hi - i); the rows of
         // timestep i sit in buffer i & 1 of the tile
-        // back waves, stage 0: close timestep i - 1 (eps, posterior update), open timestep i (layer 1)
+        // front waves, stage 0: close timestep i - 1 (eps, posterior update), open timestep i (layer 1)
         auto stage_update_first = [&](int g, int i, int par) {
             if (!has[g] || i < 0 || i > n_steps) return;
             if (i >= 1) {
@@ -410,6 +422,7 @@ __global__ __launch_bounds__(kThreads8) void card_sample_split_kernel(const Spli
             for (int r = 0; r < 16; ++r) part = fmaf(a[r], w4r[r], part);
             part += __shfl_xor(part, 32, 64);
             if (li.hh == 0) red[(g * kWaves + w) * kTileM + li.m] = part;
+            __builtin_amdgcn_s_setprio(0);
             // the update that closes this timestep (next interval) consumes draw d: a new block of four starts at
             // d % 4 == 0; a call that starts mid-loop (y_init) has not drawn its first block yet
             if (rng && t >= 1 && ((d & 3) == 0 || (i == 0 && p.y_init))) gen_block(g, (uint32_t)d >> 2);
@@ -420,16 +433,30 @@ __global__ __launch_bounds__(kThreads8) void card_sample_split_kernel(const Spli
         // (ping-pong parity of the exchange buffers = parity of the interval number 3I + k)
         for (int I = 0; I <= n_steps; ++I) {
             const int e = I & 1, o = e ^ 1;
+#ifdef CARD_SPLIT_PROFILE
+            long long pts[7];
+#endif
             relane();
-            if (back) { stage_update_first(0, I, e); stage_third(1, I - 1, e); } else { stage_second(2, I - 1, e); }
+            SPT(0);
+            if (back) { stage_third(1, I - 1, e); } else { stage_update_first(0, I, e); stage_second(2, I - 1, e); }
+            SPT(1);
             __syncthreads();
-            if (back) { stage_update_first(1, I, o); stage_third(2, I - 1, o); } else { stage_second(0, I, o); }
+            SPT(2);
+            if (back) { stage_third(2, I - 1, o); } else { stage_update_first(1, I, o); stage_second(0, I, o); }
+            SPT(3);
             __syncthreads();
-            if (back) { stage_update_first(2, I, e); stage_third(0, I, e); } else { stage_second(1, I, e); }
+            SPT(4);
+            if (back) { stage_third(0, I, e); } else { stage_update_first(2, I, e); stage_second(1, I, e); }
+            SPT(5);
             __syncthreads();
+            SPT(6);
+#ifdef CARD_SPLIT_PROFILE
+            if (blockIdx.x == 0 && lane == 0)
+                for (int i = 0; i < 6; ++i) g_split_prof[wave * 8 + i] += pts[i + 1] - pts[i];
+#endif
         }
         relane();
-        if (p.out_mode == CARD_OUT_LAST && !p.eps_only && back) {
+        if (p.out_mode == CARD_OUT_LAST && !p.eps_only && !back) {
 #pragma unroll
             for (int g = 0; g < kSets; ++g)
                 if (has[g] && rowi(g) < n_here && li.hh == 0 && w == 0) (p.out + p.n_begin)[rowi(g)] = y[g];
@@ -497,3 +524,12 @@ int split_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     }
     return CARD_OK;
 }
+
+#ifdef CARD_SPLIT_PROFILE
+// profile build only: cycles of workgroup 0, [wave][work0, wait0, work1, wait1, work2, wait2]
+extern "C" CARD_API int card_debug_split_prof(long long* host64, int reset) {
+    if (host64) HIP_TRY(hipMemcpyFromSymbol(host64, HIP_SYMBOL(g_split_prof), sizeof(long long) * 64));
+    if (reset) { long long z[64] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_split_prof), z, sizeof(z))); }
+    return CARD_OK;
+}
+#endif
