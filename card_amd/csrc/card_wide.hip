@@ -8,8 +8,9 @@
 //     wide_gemm_kernel   : h1 = x_feat * softplus(BN1(gamma1[t] * (S . W1^T + b1))),  S = (y_t | y_0_hat | 0), K = 2C -> 32
 //     wide_gemm_kernel   : h2 = softplus(BN2(gamma2[t] * (h1 . W2^T + b2)))        fp32 MFMA, fused epilogue
 //     wide_gemm_kernel   : h3 = softplus(BN3(gamma3[t] * (h2 . W3^T + b3)))
-//     wide_gemm_kernel   : eps = h3 . W4^T + b4      (W4 zero-padded to 128 rows: same kernel, bias epilogue)
-//     wide_update_kernel : posterior update of y_t (regression/diffusion_utils.py:83-89), noise, outputs
+//     wide_head_update_kernel : eps = h3 . W4^T + b4 and the posterior update of y_t (diffusion_utils.py:83-89), noise,
+//                               outputs, in one VALU launch at memory speed (up to 32 classes; above that the head is a
+//                               fourth wide_gemm_kernel launch over W4 zero-padded to 128 rows + wide_update_kernel)
 // Eval-mode BatchNorm is the per-feature affine (scale, shift); scale and log2e are folded into the per-step
 // gamma table at create time, so the epilogue is xs = fma(acc + b, g'[t], shift'); h = ln2 * softplus_l2(xs).
 //
@@ -17,7 +18,8 @@
 // waves as 2 x 2, each wave 2 x 2 v_mfma_f32_32x32x2_f32 tiles (64 accumulator VGPRs); LDS tiles are
 // [128][32 + 4 pad] floats, so one ds_read_b128 at [row][8t + 4*(lane>>5)] feeds 4 consecutive MFMAs
 // (k order inside a tile is permuted identically for both operands) and is bank-conflict free; global->LDS is
-// register-staged one tile ahead (issue loads, compute, write the other stage, one barrier per tile).
+// register-staged one tile ahead into a single LDS stage (issue loads, compute, barrier, write, barrier); four workgroups
+// per CU cover each other's barriers (see kGemmWgPerCu).
 #include "card_internal.h"
 
 using namespace card;
