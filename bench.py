@@ -138,6 +138,7 @@ def main():
         x_rows = torch.randn(a.rows, H, generator=g)
         y0_rows = torch.softmax(torch.randn(a.rows, y_dim, generator=g) * 2, 1)
         y_true = None
+        cls_labels = y0_rows.argmax(1).to(dev)
     arith = _lib.ARITH_SPLIT_BF16 if a.arith == "split" else _lib.ARITH_F32_MFMA
     if arith == _lib.ARITH_SPLIT_BF16 and not (kind == "guided" and H == 128 and y_dim == 1):
         sys.exit("--arith split is built for the hidden-128 regression sampler")
@@ -146,7 +147,7 @@ def main():
     x, y0 = x_rows.to(dev), y0_rows.to(dev)
     elem_offset = rank * N * y_dim
     from card_amd.distributed import all_reduce_sums
-    from card_amd.metrics import regression_metric_sums
+    from card_amd.metrics import regression_metric_sums, classification_metric_sums
 
     def one_step(i):
         y = sampler.run(x, y0, y0, coef, T, seed=1234 + i, elem_offset=elem_offset, out_mode=_lib.OUT_LAST, n_z=a.nz,
@@ -158,8 +159,9 @@ def main():
                 # the HIP metrics kernel (one workgroup sorts a row's n_z samples in LDS)
                 sums = regression_metric_sums(y.reshape(a.rows, a.nz, 1), y_true, tau=1.0)
             else:
-                # predicted-label histogram of the per-image mean sample (card_classification.py:1010-1020)
-                sums = torch.bincount(y.reshape(a.rows, a.nz, y_dim).mean(1).argmax(1), minlength=y_dim).double()
+                # images, correct majority votes, summed instance accuracies, t-test rejections (card_classification.py:
+                # 562-596, :1033-1060) from the HIP metrics kernel (one workgroup per image: softmax, votes, CI, t-test)
+                sums = classification_metric_sums(y, cls_labels, n_z=a.nz)
             all_reduce_sums(sums)
         return y
 

@@ -14,7 +14,7 @@ COEF_COLS = 8
 EXPORTS = (
     "card_version", "card_last_error", "card_make_coef_table", "card_sampler_create", "card_sampler_destroy",
     "card_sampler_run", "card_sampler_workspace_bytes", "card_eps_theta", "card_q_sample", "card_philox_normal",
-    "card_regression_row_metrics", "card_sampler_run_static", "card_content_hash",
+    "card_regression_row_metrics", "card_classification_row_metrics", "card_sampler_run_static", "card_content_hash",
     "card_fphi_create", "card_fphi_destroy", "card_fphi_forward",
 )
 FPHI_MAX_LAYERS, FPHI_MAX_WIDTH = 8, 1024
@@ -59,6 +59,16 @@ class MetricArgs(C.Structure):
     ]
 
 
+class ClsMetricArgs(C.Structure):
+    _fields_ = [
+        ("struct_bytes", C.c_int32), ("n_z", C.c_int32), ("n_classes", C.c_int32), ("n_states", C.c_int32),
+        ("rows", C.c_int64), ("samples", _fp), ("labels", _fp), ("scale_T", C.c_float), ("ci_lo", C.c_float),
+        ("ci_hi", C.c_float), ("ttest_alpha", C.c_float), ("label_probs", _fp), ("mean_probs", _fp), ("ci", _fp),
+        ("majority_vote", _fp), ("instance_accuracy", _fp), ("ttest_pvalue", _fp), ("ttest_reject", _fp),
+        ("sample_probs", _fp),
+    ]
+
+
 class CardError(RuntimeError):
     pass
 
@@ -90,6 +100,7 @@ def lib():
     L.card_q_sample.argtypes = [_fp, _fp, _fp, _fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_uint64,
                                 C.c_uint64, _fp, C.c_void_p]
     L.card_regression_row_metrics.argtypes = [C.POINTER(MetricArgs), C.c_void_p]
+    L.card_classification_row_metrics.argtypes = [C.POINTER(ClsMetricArgs), C.c_void_p]
     L.card_fphi_create.argtypes = [C.POINTER(FphiDesc), C.c_void_p, C.POINTER(C.c_void_p)]
     L.card_fphi_destroy.argtypes = [C.c_void_p]
     L.card_fphi_destroy.restype = None

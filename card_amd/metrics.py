@@ -71,3 +71,62 @@ def finalize(sums, n_bins=10):
     ratio = counts[:, 1:-1] / n[:, None]
     return {"rmse": (sums[:, 1] / n).sqrt(), "picp": sums[:, 2] / n, "nll": sums[:, 3] / n,
             "qice": (1.0 / n_bins - ratio).abs().mean(1)}
+
+
+def classification_row_metrics(samples, labels, *, n_z=None, scale_T=1.0, ci_range=(2.5, 97.5), ttest_alpha=0.05,
+                               return_sample_probs=False):
+    """Per-image statistics of generated classification samples: `card_classification_row_metrics`, the device side of
+    compute_and_store_cls_metrics (classification/card_classification.py:540-603).
+    samples: (rows, n_z, C), (n_states, rows, n_z, C), or the sampler's flat (rows * n_z, C) with n_z given (chain order
+    (image, z)); labels: (rows,) true classes.  Returns a dict of tensors with a leading n_states axis: label_probs,
+    mean_probs (rows, C), ci (rows, 2, C), majority_vote, ttest_reject (int32), instance_accuracy (float32),
+    ttest_pvalue (float64) and, on request, sample_probs (rows, n_z, C).  Vote ties go to the lower class index."""
+    dev = samples.device
+    _require_cuda(dev)
+    s = _dev_f32(samples, dev)
+    if s.dim() == 2:
+        if not n_z or s.shape[0] % int(n_z):
+            raise CardError(f"samples of shape {tuple(s.shape)} need n_z (a divisor of {s.shape[0]})")
+        s = s.reshape(s.shape[0] // int(n_z), int(n_z), s.shape[1])
+    if s.dim() == 3:
+        s = s.unsqueeze(0)
+    if s.dim() != 4:
+        raise CardError(f"samples: expected (rows, n_z, C) or (n_states, rows, n_z, C), got {tuple(samples.shape)}")
+    n_states, rows, nz, ncls = s.shape
+    lab = labels.to(device=dev, dtype=torch.int32).reshape(-1).contiguous()
+    if lab.numel() != rows:
+        raise CardError(f"labels has {lab.numel()} entries, samples have {rows} rows")
+    f32 = dict(device=dev, dtype=torch.float32)
+    out = dict(label_probs=torch.empty(n_states, rows, ncls, **f32), mean_probs=torch.empty(n_states, rows, ncls, **f32),
+               ci=torch.empty(n_states, rows, 2, ncls, **f32),
+               majority_vote=torch.empty(n_states, rows, device=dev, dtype=torch.int32),
+               instance_accuracy=torch.empty(n_states, rows, **f32),
+               ttest_pvalue=torch.empty(n_states, rows, device=dev, dtype=torch.float64),
+               ttest_reject=torch.empty(n_states, rows, device=dev, dtype=torch.int32))
+    if return_sample_probs:
+        out["sample_probs"] = torch.empty(n_states, rows, nz, ncls, **f32)
+    a = _lib.ClsMetricArgs()
+    a.struct_bytes = C.sizeof(_lib.ClsMetricArgs)
+    a.n_z, a.n_classes, a.n_states, a.rows = nz, ncls, n_states, rows
+    a.samples, a.labels = _ptr(s), lab.data_ptr()
+    a.scale_T, a.ci_lo, a.ci_hi, a.ttest_alpha = float(scale_T), float(ci_range[0]), float(ci_range[1]), float(ttest_alpha)
+    for k in ("label_probs", "mean_probs", "ci", "majority_vote", "instance_accuracy", "ttest_pvalue", "ttest_reject"):
+        setattr(a, k, out[k].data_ptr())
+    a.sample_probs = out["sample_probs"].data_ptr() if return_sample_probs else None
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().card_classification_row_metrics(C.byref(a), _stream(dev)), "card_classification_row_metrics")
+    return out
+
+
+def classification_metric_sums(samples, labels, **kw):
+    """Additive sums per state as float64 (n_states, 4): [n images, majority votes that are correct, sum of instance
+    accuracies, t-test rejections] -- all-reduce over ranks, divide by column 0 (card_classification.py:1033-1060)."""
+    m = classification_row_metrics(samples, labels, **kw)
+    lab = labels.to(device=m["majority_vote"].device, dtype=torch.int32).reshape(1, -1)
+    n_states, rows = m["majority_vote"].shape
+    out = torch.zeros(n_states, 4, dtype=torch.float64, device=lab.device)
+    out[:, 0] = rows
+    out[:, 1] = (m["majority_vote"] == lab).double().sum(1)
+    out[:, 2] = m["instance_accuracy"].double().sum(1)
+    out[:, 3] = m["ttest_reject"].double().sum(1)
+    return out

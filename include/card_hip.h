@@ -274,6 +274,37 @@ typedef struct card_metric_args {
 
 CARD_API int card_regression_row_metrics(const card_metric_args* args, void* stream);
 
+/* Per-image evaluation statistics of generated classification samples (one workgroup per (state, image)).
+ * Replaces the host side of compute_and_store_cls_metrics, classification/card_classification.py:540-603: for the n_z
+ * generated y vectors of an image -- raw value -(y - 1)^2 (:529-536), softmax(raw / scale_T) (:552-554), the credible
+ * interval of the raw values per class (nanquantile at PICP_range, :556-560), per-sample predicted labels and their vote
+ * proportions (:562-569), the mean probabilities (:570), the majority vote (:572), the share of samples that predict the
+ * true label (:574) and the paired two-sided t-test between the two most voted classes (:576-596, scipy ttest_rel).
+ * Ties (equal vote counts) go to the lower class index, for the majority vote and for the runner-up of the t-test
+ * (torch.argmax / argsort leave that order unspecified).  Reductions over images stay with the caller. */
+typedef struct card_cls_metric_args {
+    int32_t struct_bytes;
+    int32_t n_z;              /* samples per image (config.testing.n_samples), <= 1024 */
+    int32_t n_classes;        /* <= 1024; n_classes * (n_z + pow2ceil(n_z)) * 4 bytes must fit 144 KB of LDS */
+    int32_t n_states;         /* leading dimension of samples */
+    int64_t rows;             /* images */
+    const float* samples;     /* device (n_states, rows, n_z, n_classes): chain order (image, z) of the sampler output */
+    const int32_t* labels;    /* device (rows): true class of every image */
+    float scale_T;            /* temperature of the softmax (self.tuned_scale_T; 1 when not tuned) */
+    float ci_lo, ci_hi;       /* config.testing.PICP_range in percent (2.5, 97.5) */
+    float ttest_alpha;        /* config.testing.ttest_alpha (0.05) */
+    float* label_probs;       /* out (n_states, rows, n_classes): share of samples whose arg-max is that class */
+    float* mean_probs;        /* out (n_states, rows, n_classes): mean softmax probability */
+    float* ci;                /* out (n_states, rows, 2, n_classes): quantiles of the raw values */
+    int32_t* majority_vote;   /* out (n_states, rows) */
+    float* instance_accuracy; /* out (n_states, rows) */
+    double* ttest_pvalue;     /* out (n_states, rows): NaN when the differences have no variance (as scipy) */
+    int32_t* ttest_reject;    /* out (n_states, rows): pvalue < ttest_alpha */
+    float* sample_probs;      /* out, optional (n_states, rows, n_z, n_classes): softmax probabilities of every sample, or NULL */
+} card_cls_metric_args;
+
+CARD_API int card_classification_row_metrics(const card_cls_metric_args* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

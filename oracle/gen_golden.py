@@ -383,6 +383,72 @@ def gen_metrics(name, rows, n_z, seed, *, scaler, tau, trim, n_bins=10, picp=(2.
     print(f"{name}: rows={rows} n_z={n_z} rmse={np.sqrt(np.mean(se)):.4f} nll={np.mean(nll):.4f} qice={qice:.4f} picp={cover:.4f}")
 
 
+def reference_cls_metric_closures(T, scale_T):
+    """compute_val_before_softmax and compute_and_store_cls_metrics are closures inside Diffusion.test_image_task
+    (classification/card_classification.py:529-603): their FunctionDef nodes are pulled out of the reference source with
+    `ast` and compiled in a namespace that supplies what they close over -- `self` (num_timesteps, tuned_scale_T), the
+    per-timestep result lists, `step` (1: the plotting branch at :580 is for step 0 only) -- so the reference's own code
+    runs, unedited, without importing the runner (which needs statsmodels / torchvision)."""
+    import ast
+    from scipy.stats import ttest_rel
+    path = f"{REF}/classification/card_classification.py"
+    tree = ast.parse(open(path).read(), path)
+    want = ["compute_val_before_softmax", "compute_and_store_cls_metrics"]
+    test_fn = next(n for c in tree.body if isinstance(c, ast.ClassDef) and c.name == "Diffusion"
+                   for n in c.body if isinstance(n, ast.FunctionDef) and n.name == "test_image_task")
+    found = [n for n in test_fn.body if isinstance(n, ast.FunctionDef) and n.name in want]
+    assert [n.name for n in found] == want
+    mod = ast.fix_missing_locations(ast.Module(found, []))
+    lists = ["majority_vote_by_batch_list", "all_class_probs_by_batch_list", "label_probs_by_batch_list",
+             "label_mean_probs_by_batch_list", "instance_accuracy_by_batch_list", "CI_by_batch_list",
+             "ttest_reject_by_batch_list"]
+    ns = {"np": np, "torch": torch, "ttest_rel": ttest_rel, "step": 1, "self": NS(num_timesteps=T, tuned_scale_T=scale_T)}
+    for l in lists:
+        ns[l] = [[] for _ in range(T + 1)]
+    exec(compile(mod, path, "exec"), ns)
+    return ns
+
+
+def gen_cls_metrics(name, rows, n_z, C, seed, *, scale_T=1.0, ci=(2.5, 97.5), alpha=0.05, spread=0.35):
+    """Reference classification test metrics on seeded samples -> tests/golden/clsmetrics_*.npz (inputs + the reference's
+    outputs at metrics_t = 0 plus scipy's p-values on the same pairs).  Samples: a noisy one-hot-like y per image (as
+    reverse-diffusion outputs are: class prototypes near 1, the rest near 0), with a runner-up class of varying strength
+    so that vote counts, t-tests and intervals are not degenerate."""
+    from scipy.stats import ttest_rel
+    rng = np.random.default_rng(seed)
+    labels = rng.integers(0, C, size=rows)
+    first = np.where(rng.uniform(size=rows) < 0.8, labels, rng.integers(0, C, size=rows))
+    second = (first + 1 + rng.integers(0, max(C - 1, 1), size=rows)) % C
+    base = rng.normal(0.0, 0.08, size=(rows, 1, C))
+    base[np.arange(rows), 0, first] += 1.0
+    base[np.arange(rows), 0, second] += rng.uniform(0.2, 1.0, size=rows)
+    gen = (base + rng.normal(0.0, spread, size=(rows, n_z, C))).astype(np.float32)
+    T = 3
+    ns = reference_cls_metric_closures(T, scale_T)
+    cfg = NS(testing=NS(n_samples=n_z, PICP_range=list(ci), ttest_alpha=alpha, metrics_t=0), data=NS(num_classes=C))
+    yl = torch.from_numpy(labels.reshape(-1, 1))
+    ns["compute_and_store_cls_metrics"](cfg, yl, torch.from_numpy(gen.reshape(rows * n_z, C)), rows, T + 1)   # num_t = T + 1 <-> t = 0
+    g = lambda k: np.asarray(ns[k][0])
+    probs = g("all_class_probs_by_batch_list").reshape(rows, n_z, C)
+    label_probs = g("label_probs_by_batch_list")
+    # the pair the reference's argsort picked and scipy's p-value for it (the closure keeps only the reject flag)
+    pair = torch.from_numpy(label_probs).argsort(dim=1, descending=True)[:, :2].numpy()
+    pv = ttest_rel(np.take_along_axis(probs, pair[:, None, :1], 2)[:, :, 0],
+                   np.take_along_axis(probs, pair[:, None, 1:], 2)[:, :, 0], axis=1, alternative="two-sided").pvalue
+    srt = -np.sort(-label_probs, axis=1)
+    np.savez(os.path.join(OUT, name + ".npz"), kind="clsmetrics", rows=rows, n_z=n_z, C=C, scale_T=np.float64(scale_T),
+             ci_range=np.asarray(ci, dtype=np.float64), alpha=np.float64(alpha), gen=gen, labels=labels.astype(np.int64),
+             probs_head=probs[:8].astype(np.float32), label_probs=label_probs.astype(np.float32),
+             mean_probs=g("label_mean_probs_by_batch_list").astype(np.float32),
+             instance_accuracy=g("instance_accuracy_by_batch_list").astype(np.float32).reshape(-1),
+             ci=g("CI_by_batch_list").astype(np.float32), majority_vote=g("majority_vote_by_batch_list").astype(np.int64).reshape(-1),
+             ttest_reject=g("ttest_reject_by_batch_list").astype(np.int32).reshape(-1), ttest_pair=pair.astype(np.int64),
+             ttest_pvalue=np.asarray(pv, dtype=np.float64),
+             unique_top2=((srt[:, 0] > srt[:, 1]) & ((C < 3) | (srt[:, 1] > srt[:, min(2, C - 1)]))))
+    print(f"{name}: rows={rows} n_z={n_z} C={C} accuracy={np.mean(g('majority_vote_by_batch_list').reshape(-1) == labels):.3f} "
+          f"reject={np.mean(g('ttest_reject_by_batch_list')):.3f}")
+
+
 def gen_fphi(reg_model, name, x_dim, N, seed, hid_layers=(100, 50), use_batchnorm=False, slope=0.01):
     """regression/model.py:55-82 DeterministicFeedForwardNeuralNetwork (the guidance net f_phi of the UCI configs:
     hidden 100, 50, LeakyReLU 0.01, no batch norm, dropout 0.2 = identity in eval mode: regression/configs/uci_boston.yml:31-39).
@@ -457,6 +523,11 @@ def main():
     M("metrics_nz2", 97, 2, 4, scaler=True, tau=None, trim=(0, 100))
     M("metrics_nz100_median", 97, 100, 5, scaler=True, tau=0.5, trim=(50, 50))
     M("metrics_nz257_median", 97, 257, 6, scaler=False, tau=None, trim=(50, 50))
+    CM = lambda name, *a, **k: job(name, gen_cls_metrics, name, *a, **k)
+    CM("clsmetrics_c10_nz100", 64, 100, 10, 11)                                   # cifar10.yml / mnist.yml: 100 samples, 10 classes
+    CM("clsmetrics_c100_nz100", 20, 100, 100, 12, spread=0.25)                    # cifar100.yml
+    CM("clsmetrics_c3_nz37_T2", 50, 37, 3, 13, scale_T=2.3, ci=(5.0, 90.0), alpha=0.01)
+    CM("clsmetrics_c2_nz1000", 30, 1000, 2, 14, spread=0.6)
     job("fphi_boston", gen_fphi, reg_model, "fphi_boston", 13, 64, 41)
     job("fphi_year", gen_fphi, reg_model, "fphi_year", 90, 64, 42)
     job("fphi_bn_wide", gen_fphi, reg_model, "fphi_bn_wide", 8, 37, 43, hid_layers=(64, 200, 32), use_batchnorm=True, slope=0.2)

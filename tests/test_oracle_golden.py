@@ -116,3 +116,23 @@ def test_fphi_matches_reference(name):
     sd = {k[3:]: torch.from_numpy(v) for k, v in d.items() if k.startswith("sd.")}
     got = orc.fphi_forward(sd, torch.from_numpy(d["x"]), float(d["negative_slope"]))
     assert norm_rel_err(got, d["y"]) <= TOL
+
+
+def test_classification_metric_fixtures_are_self_consistent():
+    """tests/golden/clsmetrics_*.npz (the reference's compute_and_store_cls_metrics on seeded samples, oracle/gen_golden.py):
+    vote proportions are counts over n_z that sum to one, the stored majority vote is an arg-max of them, instance accuracy
+    is the true label's proportion, interval bounds are ordered, reject flags follow the stored p-values."""
+    import glob
+    import os
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "clsmetrics_*.npz")))
+    assert len(paths) >= 4
+    for p in paths:
+        d = np.load(p)
+        n_z, lp = int(d["n_z"]), d["label_probs"]
+        assert d["gen"].shape == (int(d["rows"]), n_z, int(d["C"]))
+        assert np.allclose(lp.sum(1), 1.0, atol=1e-6) and np.allclose(lp * n_z, np.round(lp * n_z), atol=1e-4)
+        assert np.array_equal(lp[np.arange(len(lp)), d["majority_vote"]], lp.max(1))
+        assert np.allclose(d["instance_accuracy"], lp[np.arange(len(lp)), d["labels"]])
+        assert (d["ci"][:, 0] <= d["ci"][:, 1]).all()
+        ok = ~np.isnan(d["ttest_pvalue"])
+        assert np.array_equal(d["ttest_reject"][ok], (d["ttest_pvalue"][ok] < float(d["alpha"])).astype(np.int32))
