@@ -20,7 +20,8 @@ from .sampler import (coef_on_device, make_coef_table, sampler_for, x_features, 
 # every public name of regression/diffusion_utils.py and classification/diffusion_utils.py (the runners star-import the
 # module: regression/card_regression.py:16 uses kld at :685), plus this package's extras
 __all__ = ["make_beta_schedule", "extract", "q_sample", "p_sample", "p_sample_t_1to0", "p_sample_loop", "kld",
-           "y_0_reparam", "p_sample_loop_with_eval", "p_sample_loop_with_y", "p_sample_loop_from_x", "p_sample_loop_repeated"]
+           "y_0_reparam", "p_sample_loop_with_eval", "p_sample_loop_with_y", "p_sample_loop_from_x", "p_sample_loop_repeated",
+           "p_sample_loop_with_cls_metrics"]
 
 
 def make_beta_schedule(schedule="linear", num_timesteps=1000, start=1e-5, end=1e-2):
@@ -391,3 +392,27 @@ def p_sample_loop_with_eval(model, x, y_0_hat, y_T_mean, n_steps, alphas, one_mi
         if at + 1 in want:
             on_state(cur, at + 1)
     return cur
+
+
+def p_sample_loop_with_cls_metrics(model, x, y_0_hat, labels, n_steps, alphas, one_minus_alphas_bar_sqrt, *, n_samples,
+                                   y_T_mean=None, num_ts=None, scale_T=1.0, ci_range=(2.5, 97.5), ttest_alpha=0.05,
+                                   seed=None, elem_offset=0):
+    """One test minibatch of Diffusion.test_image_task (classification/card_classification.py:997-1026) without leaving
+    the GPU: x / y_0_hat / labels are per IMAGE (the n_samples tiling of :1013-1020 happens inside the kernels), the chain
+    is sampled with `p_sample_loop_with_eval` and every requested state (num_t values, default: y_0 only = metrics_t 0)
+    goes through `card_classification_row_metrics` instead of compute_and_store_cls_metrics' host code.
+    Returns {num_t: dict of per-image tensors} (card_amd.metrics.classification_row_metrics)."""
+    from .metrics import classification_row_metrics
+    T = int(n_steps)
+    want = [T + 1] if num_ts is None else [int(v) for v in num_ts]
+    mu = y_0_hat if y_T_mean is None else y_T_mean
+    out = {}
+
+    def on_state(cur_y, num_t):
+        m = classification_row_metrics(cur_y, labels, n_z=int(n_samples), scale_T=scale_T, ci_range=ci_range,
+                                       ttest_alpha=ttest_alpha)
+        out[num_t] = {k: v[0] for k, v in m.items()}
+
+    p_sample_loop_with_eval(model, x, y_0_hat, mu, T, alphas, one_minus_alphas_bar_sqrt, on_state, num_ts=want, seed=seed,
+                            elem_offset=elem_offset, n_z=int(n_samples))
+    return out

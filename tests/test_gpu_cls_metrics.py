@@ -79,3 +79,26 @@ def test_degenerate_rows_and_limits():
     assert (one["majority_vote"] == 0).all() and torch.allclose(one["mean_probs"], torch.ones_like(one["mean_probs"]))
     with pytest.raises(CardError, match="LDS"):
         classification_row_metrics(torch.zeros(1, 1000, 100, device=DEV), torch.zeros(1, device=DEV))
+
+
+def test_fused_test_batch_helper_equals_sampling_then_metrics():
+    """p_sample_loop_with_cls_metrics (one classification test minibatch on the device: in-kernel tiling, sampling, metrics
+    of the requested states) == p_sample_loop on the same seed followed by classification_row_metrics."""
+    import card_amd
+    from tests.helpers import load_golden
+    from tests.test_gpu_cls import RefShapedCls
+    g = load_golden("cls_mnist_T50")
+    m = RefShapedCls(g["sd"]).to(DEV).eval()
+    T, rows, n_s = g["T"], 9, 33
+    xf, y0 = g["x_feat"][:rows].to(DEV), g["y0hat"][:rows].to(DEV)
+    labels = y0.argmax(1)
+    al, om = g["alphas"].to(DEV), g["omabs"].to(DEV)
+    got = card_amd.p_sample_loop_with_cls_metrics(m, xf, y0, labels, T, al, om, n_samples=n_s, num_ts=[1, 20, T + 1], seed=5)
+    assert sorted(got) == [1, 20, T + 1]
+    full = card_amd.p_sample_loop(m, xf, y0, y0, T, al, om, seed=5, n_z=n_s)
+    for num_t, mm in got.items():
+        ref = classification_row_metrics(full[num_t - 1], labels, n_z=n_s)
+        for k, v in mm.items():
+            assert torch.equal(v, ref[k][0]) or (k == "ttest_pvalue" and torch.equal(torch.isnan(v), torch.isnan(ref[k][0]))), (num_t, k)
+    default = card_amd.p_sample_loop_with_cls_metrics(m, xf, y0, labels, T, al, om, n_samples=n_s, seed=5)
+    assert list(default) == [T + 1] and torch.equal(default[T + 1]["majority_vote"], got[T + 1]["majority_vote"])
