@@ -14,6 +14,7 @@ from .diffusion_utils import (  # noqa: F401
     p_sample_loop_repeated,
     p_sample_loop_with_eval,
     p_sample_loop_with_cls_metrics,
+    p_sample_loop_with_reg_metrics,
     p_sample_loop_with_y,
     p_sample_t_1to0,
     q_sample,

@@ -21,7 +21,7 @@ from .sampler import (coef_on_device, make_coef_table, sampler_for, x_features, 
 # module: regression/card_regression.py:16 uses kld at :685), plus this package's extras
 __all__ = ["make_beta_schedule", "extract", "q_sample", "p_sample", "p_sample_t_1to0", "p_sample_loop", "kld",
            "y_0_reparam", "p_sample_loop_with_eval", "p_sample_loop_with_y", "p_sample_loop_from_x", "p_sample_loop_repeated",
-           "p_sample_loop_with_cls_metrics"]
+           "p_sample_loop_with_cls_metrics", "p_sample_loop_with_reg_metrics"]
 
 
 def make_beta_schedule(schedule="linear", num_timesteps=1000, start=1e-5, end=1e-2):
@@ -416,3 +416,23 @@ def p_sample_loop_with_cls_metrics(model, x, y_0_hat, labels, n_steps, alphas, o
     p_sample_loop_with_eval(model, x, y_0_hat, mu, T, alphas, one_minus_alphas_bar_sqrt, on_state, num_ts=want, seed=seed,
                             elem_offset=elem_offset, n_z=int(n_samples))
     return out
+
+
+def p_sample_loop_with_reg_metrics(model, f_phi, x, y_true, n_steps, alphas, one_minus_alphas_bar_sqrt, *, n_z, states=None,
+                                   noise_prior=False, n_bins=10, picp_range=(2.5, 97.5), trimmed_mean_range=(0.0, 100.0),
+                                   y_scale=1.0, y_shift=0.0, tau=None, seed=None, elem_offset=0):
+    """One test minibatch of the regression Diffusion.test (regression/card_regression.py:1014-1074) without leaving the
+    GPU: f_phi, the n_z tiling and the sampling in one call (`p_sample_loop_from_x`), then the per-row statistics of the
+    requested trajectory states (list positions as in the reference: 0 = y_T ... n_steps = y_0; default y_0 only) from
+    `card_regression_row_metrics` instead of compute_prediction_SE / compute_true_coverage_by_gen_QI / compute_PICP /
+    compute_batch_NLL on host copies.  y_true: (rows,) normalised targets.
+    Returns (dict of (n_states, rows) tensors se / nll / qice_bin / picp_in, y_0_hat (rows, 1))."""
+    from .metrics import regression_row_metrics
+    T = int(n_steps)
+    st = [T] if states is None else [int(v) for v in states]
+    ys, y0hat = p_sample_loop_from_x(model, f_phi, x, T, alphas, one_minus_alphas_bar_sqrt, n_z=n_z, noise_prior=noise_prior,
+                                     seed=seed, elem_offset=elem_offset, states=st)
+    rows = int(x.shape[0])
+    m = regression_row_metrics(ys.reshape(len(st), rows, int(n_z)), y_true, n_bins=n_bins, picp_range=picp_range,
+                               trimmed_mean_range=trimmed_mean_range, y_scale=y_scale, y_shift=y_shift, tau=tau)
+    return m, y0hat

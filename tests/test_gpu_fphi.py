@@ -153,6 +153,30 @@ def test_shim_p_sample_loop_from_x():
     assert not torch.equal(y0hat2, y0hat)
 
 
+def test_fused_regression_test_batch_helper():
+    """card_amd.p_sample_loop_with_reg_metrics (f_phi + tiling + sampling + per-row metrics of the requested states, one
+    call per test minibatch: regression/card_regression.py:1014-1074) == p_sample_loop_from_x followed by
+    regression_row_metrics on the same states, bit for bit."""
+    from card_amd.metrics import regression_row_metrics
+    g = load_golden("reg_boston_T50")
+    d = load_raw("fphi_boston")
+    net, _ = ref_shaped_fphi(d)
+    net = net.to(DEV)
+    model = RefShapedGuided(g["sd"], True, True).to(DEV).eval()
+    x = torch.from_numpy(d["x"]).to(DEV)
+    rows, T, n_z = x.shape[0], g["T"], 50
+    y_true = torch.randn(rows, generator=torch.Generator().manual_seed(2)).to(DEV)
+    al, om = g["alphas"].to(DEV), g["omabs"].to(DEV)
+    kw = dict(y_scale=9.2, y_shift=22.5, tau=None, trimmed_mean_range=(0.0, 100.0))
+    m, y0hat = card_amd.p_sample_loop_with_reg_metrics(model, net, x, y_true, T, al, om, n_z=n_z, states=[0, T // 2, T], seed=3, **kw)
+    assert m["se"].shape == (3, rows) and y0hat.shape == (rows, 1)
+    ys, y0b = card_amd.p_sample_loop_from_x(model, net, x, T, al, om, n_z=n_z, seed=3, states=[0, T // 2, T])
+    ref = regression_row_metrics(ys.reshape(3, rows, n_z), y_true, **kw)
+    assert torch.equal(y0hat, y0b) and all(torch.equal(m[k], ref[k]) for k in ref)
+    last, _ = card_amd.p_sample_loop_with_reg_metrics(model, net, x, y_true, T, al, om, n_z=n_z, seed=3, **kw)
+    assert all(torch.equal(last[k][0], m[k][2]) for k in last) and torch.isfinite(last["nll"]).all()
+
+
 def test_fphi_argument_errors():
     g = load_golden("reg_boston_T50")
     s = Sampler.from_state_dict(g["sd"], device=DEV)
