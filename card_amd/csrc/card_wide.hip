@@ -167,12 +167,23 @@ __device__ __forceinline__ void wide_gemm_tile(const float* __restrict__ A, cons
         __syncthreads();
     }
     // epilogue: C/D map of the 32x32 tile: column = lane & 31 (feature), row = (r&3) + 8(r>>2) + 4(lane>>5) (chain)
+    constexpr bool kMul = EPI == EPI_SOFTPLUS_MUL || EPI == EPI_SCALE_MUL;
+    // Hadamard operand: with in-kernel row tiling (n_z >= 64: every classification config) the rows of a tile come from at
+    // most three input rows, so a lane needs three values of its column, not one global load per output element
+    const int xr0 = kMul ? mrow[0] : 0;
+    const bool few = kMul && mrow[TBM - 1] - xr0 <= 2;
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int col = n0 + wn * 32 * TN + b * 32 + li;
         const float bb = bias[col];
         float gg = 0.0f, ss = 0.0f;
         if (EPI != EPI_BIAS) { gg = g[col]; ss = sh[col]; }
+        float mv[3] = {0.0f, 0.0f, 0.0f};
+        if (few) {
+            const int xl = mrow[TBM - 1];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) mv[j] = mul[(long long)(xr0 + j <= xl ? xr0 + j : xl) * ldo + col];
+        }
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
 #pragma unroll
@@ -183,7 +194,14 @@ __device__ __forceinline__ void wide_gemm_tile(const float* __restrict__ A, cons
                 if (EPI == EPI_SOFTPLUS || EPI == EPI_SOFTPLUS_MUL) v = kLn2 * softplus_l2(fmaf(v, gg, ss));
                 if (EPI == EPI_SCALE || EPI == EPI_SCALE_MUL) v = gg * v;      // gamma[t] * lin(x), builder.py:63-65
                 if (row < M) {
-                    if (EPI == EPI_SOFTPLUS_MUL || EPI == EPI_SCALE_MUL) v *= mul[(long long)mrow[lr] * ldo + col];   // Hadamard with x_feat (model.py:87)
+                    if (kMul) {                                                 // Hadamard with x_feat (model.py:87)
+                        if (few) {
+                            const int dxr = mrow[lr] - xr0;
+                            v *= dxr == 0 ? mv[0] : (dxr == 1 ? mv[1] : mv[2]);
+                        } else {
+                            v *= mul[(long long)mrow[lr] * ldo + col];
+                        }
+                    }
                     out[row * ldo + col] = v;
                 }
             }
