@@ -76,7 +76,11 @@ namespace {
 
 // BN affine + softplus of a 32-feature x 32-chain tile, staged over its 16 registers (see card_guided.hip)
 __device__ __forceinline__ void epilogue_bn(f32x16& acc, const float* gl, const float* sl) {
-    float xs[16], e[16];
+    // The stages are fenced with empty asm statements that take all 16 values at once: __builtin_amdgcn_sched_barrier
+    // alone does not pin pure arithmetic (instruction selection orders it by data dependence only), and where a consumer
+    // follows element by element -- the lin4 MFMAs after layer 3 -- the compiler had sunk each element's
+    // fma -> exp -> add -> log -> med3 chain in front of its MFMA, every transcendental latency exposed.
+    f32x16 xs, e;
     __builtin_amdgcn_s_setprio(kPrioValu);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -84,18 +88,19 @@ __device__ __forceinline__ void epilogue_bn(f32x16& acc, const float* gl, const 
 #pragma unroll
         for (int k = 0; k < 4; ++k) xs[4 * q + k] = fmaf(acc[4 * q + k], g[k], sh[k]);
     }
-    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+v"(xs));
 #pragma unroll
     for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(xs[r]);
-    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+v"(e));
 #pragma unroll
     for (int r = 0; r < 16; ++r) e[r] = 1.0f + e[r];
-    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+v"(e));
 #pragma unroll
     for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_logf(e[r]);
-    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+v"(e));
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = __builtin_amdgcn_fmed3f(e[r], xs[r], kSpThresh);
+    asm volatile("" : "+v"(acc));
     __builtin_amdgcn_s_setprio(kPrioMfma);
 }
 
