@@ -395,3 +395,36 @@ def test_per_timestep_shim_loop_equals_fused_loop_and_pins_nothing():
     del xf
     gc.collect()
     assert ref() is None and du._step_ctx is None
+
+
+@pytest.mark.parametrize("F,C", [(2048, 100), (2048, 1000)])
+def test_imagenet_head_at_its_real_dimensions_against_oracle(F, C):
+    """imagenet/card/builder.py:69-84 at the sizes the ImageNet tree runs (feature_dim 2048 = ResNet-50 features; 100
+    classes is its default, 1000 the full label set): layer 1 with K = 2C = 200 / 2000 columns of state, the head as a
+    GEMM launch (more than 32 classes), T = 10 with the tree's beta range (main.py:83-88).  Seeded random weights against
+    the CPU oracle (the fixture inet_head_T10 pins the same code path at 20 classes against the reference itself)."""
+    T, N = 10, 24
+    gen = torch.Generator().manual_seed(F + C)
+    lin = lambda o, i, s=1.0: (torch.randn(o, i, generator=gen) * (s / i ** 0.5), torch.randn(o, generator=gen) * 0.1)
+    sd = {}
+    for name, (o, i) in {"lin1.lin": (F, 2 * C), "lin2.lin": (F, F), "lin3": (C, F)}.items():
+        w, b = lin(o, i, 0.3 if name == "lin3" else 1.0)
+        sd[name + ".weight"], sd[name + ".bias"] = w, b
+    sd["lin1.embed.weight"] = torch.rand(T, F, generator=gen)
+    sd["lin2.embed.weight"] = torch.rand(T, F, generator=gen)
+    w = orc.LinearHeadWeights.from_state_dict(sd)
+    xf = torch.randn(N, F, generator=gen)
+    y0 = torch.softmax(torch.randn(N, C, generator=gen) * 2, 1)
+    noise = torch.randn(T, N, C, generator=gen)
+    alphas, _, omabs = orc.make_schedule("linear", T, 0.01, 0.95)
+    want = torch.stack(orc.p_sample_loop(w, xf, y0, y0, T, alphas, omabs, noise), 0)
+    s = Sampler.from_imagenet_head_state_dict(sd, device=DEV)
+    coef = cuda(make_coef_table(alphas, omabs))
+    got = s.run(cuda(xf), cuda(y0), cuda(y0), coef, T, noise=cuda(noise), out_mode=_lib.OUT_ALL).cpu()
+    worst = max(norm_rel_err(got[k], want[k]) for k in range(T + 1))
+    print(f"inet head F={F} C={C}: worst per-state norm-rel err {worst:.3e}, max|y| {want.abs().max():.2f}")
+    assert worst <= TOL
+    # in-kernel repeats (save_prediction, main.py:555-566) == pre-tiled rows
+    a = s.run(cuda(xf[:3]), cuda(y0[:3]), cuda(y0[:3]), coef, T, seed=7, n_z=9)
+    b = s.run(cuda(xf[:3].repeat_interleave(9, 0)), cuda(y0[:3].repeat_interleave(9, 0)), cuda(y0[:3].repeat_interleave(9, 0)), coef, T, seed=7)
+    assert torch.equal(a, b) and torch.isfinite(a).all()
