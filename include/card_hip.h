@@ -199,7 +199,7 @@ typedef struct card_run_args {
 } card_run_args;
 
 /* Run timesteps t_hi ... t_lo of the reverse process for N independent chains (persistent kernels: one launch per
- * ~1M / ~262k chains for all timesteps; GEMM back end: five launches per timestep and chunk).
+ * ~1M / ~262k chains for all timesteps; GEMM back end: four launches per timestep and chunk, five above 32 classes).
  * Replaces: p_sample_loop (regression/diffusion_utils.py:107-119, classification/diffusion_utils.py:119-144)
  * with y_init == NULL, t_hi = T-1, t_lo = 0;  p_sample (:57-90) with t_hi = t_lo = t >= 1;
  * p_sample_t_1to0 (:94-104) with t_hi = t_lo = 0. */
