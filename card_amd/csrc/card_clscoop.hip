@@ -31,7 +31,11 @@ constexpr int kYLd = kCmax + 4;    // ys / partial-tile row stride
 constexpr int kGRow = 3 * kF;
 constexpr int kTab = 6 * kF + kCmax;                 // b1|b2|b3 | shift1|shift2|shift3 (log2 units) | b4
 constexpr int kZFloats = 4 * kTileM * kYLd;          // normals of a tile's current draw block: [draw & 3][chain][class]
-constexpr int kTileLdsFloats = 2 * kTileM * kExLd + kTileM * kYLd + kWaves * kTileM * kYLd + 2 * kGRow + kZFloats;   // per tile position
+constexpr int kExBuf = kWaves * kTileM * kYLd;        // one activation exchange buffer [32][132], sized for its alias: the four
+                                                      // lin4 partial tiles [4][32][36] (written after layer 2 has read the buffer,
+                                                      // read before layer 1 writes it again)
+constexpr int kC1Floats = kF * kTileM;                // hoisted layer-1 tile, [wave][q][lane][4]
+constexpr int kTileLdsFloats = 2 * kExBuf + kTileM * kYLd + 2 * kGRow + kZFloats + kC1Floats;   // per tile position
 constexpr int kGmax = 2;                             // tile positions per workgroup
 constexpr long long kChunkTiles = 8192;              // tiles per sliced chunk: bounds the hand-over buffer (262 144 chains)
 __host__ __device__ constexpr int lds_floats(int G) { return G * kTileLdsFloats + kTab; }
@@ -159,12 +163,12 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
     const int n_steps = p.t_hi - p.t_lo + 1;
 
     // ---- the G tile positions of this workgroup
-    float* ex[G]; float* ys[G]; float* red[G]; float* gsl[G]; float* zbuf[G];
+    float* ex[G]; float* ys[G]; float* red[G]; float* gsl[G]; float* zbuf[G]; float* c1l[G];
     float* exw[G]; const float* exr[G]; float* ysw[G]; const float* ysr[G];
     bool active[G], valid[G], first_seg[G], last_seg[G];
     long long row[G], rc[G], rr[G];
     int th[G], cnt[G], gcur[G];
-    f32x16 c1[G], xf[G];
+    f32x16 xf[G];
     float yv[G][4], mu[G][4];
     uint32_t zblock[G];
     int n_iter = 0;
@@ -172,10 +176,11 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
     for (int g = 0; g < G; ++g) {
         float* base = lds + g * kTileLds;
         ex[g] = base;                                        // 2 x [32][132] activations
-        ys[g] = ex[g] + 2 * kTileM * kExLd;                  // [32][36] y_t, chain-major
-        red[g] = ys[g] + kTileM * kYLd;                      // [4][32][36] lin4 partial tiles
-        gsl[g] = red[g] + kWaves * kTileM * kYLd;            // 2 gamma rows
+        ys[g] = ex[g] + 2 * kExBuf;                          // [32][36] y_t, chain-major
+        red[g] = ex[g];                                      // [4][32][36] lin4 partial tiles: alias of exchange buffer 0
+        gsl[g] = ys[g] + kTileM * kYLd;                      // 2 gamma rows
         zbuf[g] = gsl[g] + 2 * kGRow;                        // [4][32][36] normals of the current draw block
+        c1l[g] = zbuf[g] + kZFloats + (w * 4 * 64 + lane) * 4;   // this lane's 16 values of the hoisted layer-1 tile: + q * 256
         exw[g] = ex[g] + m * kExLd + 32 * w + 4 * hh;
         exr[g] = ex[g] + m * kExLd + 4 * hh;
         ysw[g] = ys[g] + m * kYLd + c0;
@@ -242,12 +247,14 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         if (!active[g]) continue;
+        f32x16 c1;                                           // hoisted static part of layer 1, parked in LDS (each lane reads
+                                                             // back only what it wrote itself: no barrier)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 b = lds4(tb + 8 * q);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                c1[g][4 * q + k] = b[k];
+                c1[4 * q + k] = b[k];
                 xf[g][4 * q + k] = p.xfeat[rr[g] * kF + 32 * w + 8 * q + 4 * hh + k];
             }
         }
@@ -257,10 +264,13 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int c = 8 * q + 4 * hh + e;
-                    c1[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], c < C ? p.y0hat[rr[g] * C + c] : 0.0f, c1[g], 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], c < C ? p.y0hat[rr[g] * C + c] : 0.0f, c1, 0, 0, 0);
                 }
             }
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<f32x4*>(c1l[g] + q * 256) = f32x4{c1[4 * q + 0], c1[4 * q + 1], c1[4 * q + 2], c1[4 * q + 3]};
 #pragma unroll
         for (int k = 0; k < 4; ++k) mu[g][k] = c0 + k < C ? p.ytmean[rr[g] * C + c0 + k] : 0.0f;
         if (!first_seg[g]) {
@@ -289,7 +299,7 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
     auto publish = [&](int g, const f32x16& a, int buf) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<f32x4*>(exw[g] + buf * kTileM * kExLd + 8 * q) = f32x4{a[4 * q + 0], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+            *reinterpret_cast<f32x4*>(exw[g] + buf * kExBuf + 8 * q) = f32x4{a[4 * q + 0], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
     };
     auto hidden = [&](int g, const float (&A)[64], int buf, int layer, const float* gl) -> f32x16 {
         f32x16 acc;
@@ -300,7 +310,7 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const f32x4 h = lds4(exr[g] + buf * kTileM * kExLd + 32 * (i >> 2) + 8 * (i & 3));
+            const f32x4 h = lds4(exr[g] + buf * kExBuf + 32 * (i >> 2) + 8 * (i & 3));
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * i + e], h[e], acc, 0, 0, 0);
         }
@@ -345,7 +355,12 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
                 }
             }
             // layer 1 (model.py:82-87): c1 + W1[:, 0:C] . y_t, BN, softplus, Hadamard with x_feat
-            f32x16 acc = c1[g];
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = lds4(c1l[g] + q * 256);
+                acc[4 * q + 0] = v[0]; acc[4 * q + 1] = v[1]; acc[4 * q + 2] = v[2]; acc[4 * q + 3] = v[3];
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (q < p.nq1) {
