@@ -130,3 +130,59 @@ def classification_metric_sums(samples, labels, **kw):
     out[:, 2] = m["instance_accuracy"].double().sum(1)
     out[:, 3] = m["ttest_reject"].double().sum(1)
     return out
+
+
+def classification_test_sums(m, labels, *, n_bins=10, state=0):
+    """Additive test-set sums from per-image statistics (`classification_row_metrics` output or the same arrays from
+    anywhere; torch tensors on any device).  Everything Diffusion.test_image_task reports after its loop is a function
+    of these sums, so shards / batches / GPUs just add them (all-reduce) and call `finalize_classification`:
+    compute_quantile_metrics (classification/card_classification.py:673-741), compute_ttest_metrics (:743-822), PAvPU
+    (:1076-1081), NLL (:1092-1094) and ECE (:1096-1125).
+    Returns float64 tensors: per_class (C, 6) = [n, correct, rejected, correct & rejected, sum CI width of the true class
+    over correct predictions, ... over incorrect ones]; ece_bins (n_bins + 1, 3) = [count, correct, sum confidence] by the
+    reference's bin membership; hist (n_bins,) = torch.histogram counts of the confidences; nll_sum (1,)."""
+    pick = lambda k: m[k][state] if m[k].dim() > (3 if k == "ci" else (2 if k in ("mean_probs", "label_probs") else 1)) else m[k]
+    mv, rej = pick("majority_vote").long().reshape(-1), pick("ttest_reject").bool().reshape(-1)
+    ci, mp = pick("ci").float(), pick("mean_probs").float()
+    dev = mp.device
+    lab = labels.to(dev).long().reshape(-1)
+    C = mp.shape[-1]
+    cor = mv == lab
+    ciw_true = (ci[:, 1] - ci[:, 0]).gather(1, lab[:, None])[:, 0].double()
+    cols = torch.stack([torch.ones_like(ciw_true), cor.double(), rej.double(), (cor & rej).double(),
+                        ciw_true * cor.double(), ciw_true * (~cor).double()], 1)
+    per_class = torch.zeros(C, 6, dtype=torch.float64, device=dev).index_add_(0, lab, cols)
+    conf = mp.gather(1, mv[:, None])[:, 0]                                    # confidence: mean probability of the voted class
+    nll_sum = -torch.log(mp.gather(1, lab[:, None])[:, 0]).double().sum().reshape(1)
+    edges = torch.linspace(0, 1, n_bins + 1, device=dev)[1:]
+    memb = ((conf[:, None] - edges) >= 0).sum(1)                              # 0 .. n_bins (:1104)
+    ece_cols = torch.stack([torch.ones_like(conf, dtype=torch.float64), cor.double(), conf.double()], 1)
+    ece_bins = torch.zeros(n_bins + 1, 3, dtype=torch.float64, device=dev).index_add_(0, memb, ece_cols)
+    hb = torch.clamp((conf.double() * n_bins).floor().long(), 0, n_bins - 1)  # torch.histogram(bins, range=(0, 1)): last bin closed
+    hist = torch.zeros(n_bins, dtype=torch.float64, device=dev).index_add_(0, hb, torch.ones_like(conf, dtype=torch.float64))
+    return {"per_class": per_class, "ece_bins": ece_bins, "hist": hist, "nll_sum": nll_sum}
+
+
+def finalize_classification(sums):
+    """The numbers test_image_task logs, from (summed) `classification_test_sums`.  Means over empty groups are NaN, as the
+    reference's `.mean()` of an empty selection."""
+    pc, eb, hist = sums["per_class"].double(), sums["ece_bins"].double(), sums["hist"].double()
+    n, cor, rej, cr, w_cor, w_inc = (pc[:, i] for i in range(6))
+    N, n_cor, n_rej, n_cr = n.sum(), cor.sum(), rej.sum(), cr.sum()
+    n_bins = hist.numel()
+    acc_b, conf_b = eb[:n_bins, 1] / eb[:n_bins, 0], eb[:n_bins, 2] / eb[:n_bins, 0]
+    cal = torch.where(eb[:n_bins, 0] > 0, (acc_b - conf_b).abs(), torch.zeros_like(acc_b))
+    return {
+        "accuracy": n_cor / N,
+        "accuracy_by_class": cor / n,                                          # maj_vote_acc_by_class
+        "ci_width_correct": w_cor.sum() / n_cor, "ci_width_incorrect": w_inc.sum() / (N - n_cor),
+        "ci_width_correct_by_class": w_cor / cor, "ci_width_incorrect_by_class": w_inc / (n - cor),
+        "reject_rate_correct": n_cr / n_cor, "reject_rate_incorrect": (n_rej - n_cr) / (N - n_cor),
+        "reject_rate_correct_by_class": cr / cor, "reject_rate_incorrect_by_class": (rej - cr) / (n - cor),
+        "reject_rate_by_class": rej / n,
+        "accuracy_rejected": n_cr / n_rej, "accuracy_not_rejected": (n_cor - n_cr) / (N - n_rej),
+        "accuracy_rejected_by_class": cr / rej, "accuracy_not_rejected_by_class": (cor - cr) / (n - rej),
+        "pavpu": (n_cr + (N - n_cor - (n_rej - n_cr))) / N,                    # (n_ac + n_iu) / n
+        "nll": sums["nll_sum"].double().sum() / N,
+        "ece": ((hist / N) * cal).sum(),
+    }

@@ -384,28 +384,40 @@ def gen_metrics(name, rows, n_z, seed, *, scaler, tau, trim, n_bins=10, picp=(2.
 
 
 def reference_cls_metric_closures(T, scale_T):
-    """compute_val_before_softmax and compute_and_store_cls_metrics are closures inside Diffusion.test_image_task
-    (classification/card_classification.py:529-603): their FunctionDef nodes are pulled out of the reference source with
-    `ast` and compiled in a namespace that supplies what they close over -- `self` (num_timesteps, tuned_scale_T), the
-    per-timestep result lists, `step` (1: the plotting branch at :580 is for step 0 only) -- so the reference's own code
-    runs, unedited, without importing the runner (which needs statsmodels / torchvision)."""
+    """compute_val_before_softmax, compute_and_store_cls_metrics, compute_quantile_metrics and compute_ttest_metrics are
+    closures inside Diffusion.test_image_task (classification/card_classification.py:529-822): their FunctionDef nodes are
+    pulled out of the reference source with `ast` and compiled in a namespace that supplies what they close over -- `self`
+    (num_timesteps, tuned_scale_T), the per-timestep result lists, `step` (1: the plotting branch at :580 is for step 0
+    only), cast_label_to_one_hot_and_prototype (its FunctionDef from classification/utils.py, same way) -- so the
+    reference's own code runs, unedited, without importing the runner (which needs statsmodels / torchvision).
+    ns["tail"] holds the statements of test_image_task from `majority_vote_incorrectness = ...` (:1075) to `ECE_t = ...`
+    (:1123): PAvPU, NLL and ECE, compiled as a module to exec in a namespace that defines their inputs."""
     import ast
+    import logging
     from scipy.stats import ttest_rel
     path = f"{REF}/classification/card_classification.py"
     tree = ast.parse(open(path).read(), path)
-    want = ["compute_val_before_softmax", "compute_and_store_cls_metrics"]
+    want = ["compute_val_before_softmax", "compute_and_store_cls_metrics", "compute_quantile_metrics", "compute_ttest_metrics"]
     test_fn = next(n for c in tree.body if isinstance(c, ast.ClassDef) and c.name == "Diffusion"
                    for n in c.body if isinstance(n, ast.FunctionDef) and n.name == "test_image_task")
     found = [n for n in test_fn.body if isinstance(n, ast.FunctionDef) and n.name in want]
     assert [n.name for n in found] == want
-    mod = ast.fix_missing_locations(ast.Module(found, []))
+    upath = f"{REF}/classification/utils.py"
+    cast = next(n for n in ast.parse(open(upath).read(), upath).body
+                if isinstance(n, ast.FunctionDef) and n.name == "cast_label_to_one_hot_and_prototype")
+    mod = ast.fix_missing_locations(ast.Module([cast] + found, []))
     lists = ["majority_vote_by_batch_list", "all_class_probs_by_batch_list", "label_probs_by_batch_list",
              "label_mean_probs_by_batch_list", "instance_accuracy_by_batch_list", "CI_by_batch_list",
              "ttest_reject_by_batch_list"]
-    ns = {"np": np, "torch": torch, "ttest_rel": ttest_rel, "step": 1, "self": NS(num_timesteps=T, tuned_scale_T=scale_T)}
+    ns = {"np": np, "torch": torch, "nn": torch.nn, "ttest_rel": ttest_rel, "logging": logging, "step": 1,
+          "self": NS(num_timesteps=T, tuned_scale_T=scale_T)}
     for l in lists:
         ns[l] = [[] for _ in range(T + 1)]
     exec(compile(mod, path, "exec"), ns)
+    tgt = lambda n: n.targets[0].id if isinstance(n, ast.Assign) and isinstance(n.targets[0], ast.Name) else None
+    i0 = next(i for i, n in enumerate(test_fn.body) if tgt(n) == "majority_vote_incorrectness")
+    i1 = next(i for i, n in enumerate(test_fn.body) if tgt(n) == "ECE_t")
+    ns["tail"] = compile(ast.fix_missing_locations(ast.Module(test_fn.body[i0:i1 + 1], [])), path, "exec")
     return ns
 
 
@@ -435,6 +447,22 @@ def gen_cls_metrics(name, rows, n_z, C, seed, *, scale_T=1.0, ci=(2.5, 97.5), al
     pair = torch.from_numpy(label_probs).argsort(dim=1, descending=True)[:, :2].numpy()
     pv = ttest_rel(np.take_along_axis(probs, pair[:, None, :1], 2)[:, :, 0],
                    np.take_along_axis(probs, pair[:, None, 1:], 2)[:, :, 0], axis=1, alternative="two-sided").pvalue
+    # test-set level: compute_quantile_metrics / compute_ttest_metrics on the closure's own per-image outputs, then the
+    # PAvPU / NLL / ECE statements of test_image_task
+    mv_t, rej_t = g("majority_vote_by_batch_list"), g("ttest_reject_by_batch_list")
+    cfg2 = NS(testing=NS(n_samples=n_z, PICP_range=list(ci), ttest_alpha=alpha, metrics_t=0, n_bins=10), data=NS(num_classes=C))
+    acc_c, ciw_cor_c, ciw_inc_c = ns["compute_quantile_metrics"](cfg2, g("CI_by_batch_list"), mv_t.flatten(), labels)
+    _, rej_cor_c, rej_inc_c, rej_c, acc_rej_c, acc_nrej_c = ns["compute_ttest_metrics"](cfg2, rej_t, mv_t.flatten(), labels)
+    all_true = labels.reshape(-1, 1)
+    tail = {"np": np, "torch": torch, "logging": __import__("logging"), "config": cfg2, "majority_vote_correctness": (mv_t == all_true),
+            "ttest_reject_t": rej_t, "label_probs_by_batch_list": ns["label_probs_by_batch_list"],
+            "label_mean_probs_by_batch_list": ns["label_mean_probs_by_batch_list"], "all_true_y_labels": all_true,
+            "majority_vote_t": mv_t}
+    exec(ns["tail"], tail)
+    ds = dict(ds_acc_by_class=acc_c, ds_ciw_cor_by_class=ciw_cor_c, ds_ciw_inc_by_class=ciw_inc_c, ds_rej_cor_by_class=rej_cor_c,
+              ds_rej_inc_by_class=rej_inc_c, ds_rej_by_class=rej_c, ds_acc_rej_by_class=acc_rej_c, ds_acc_nrej_by_class=acc_nrej_c,
+              ds_pavpu=float(tail["PAvPU"]), ds_nll=float(tail["NLL_t"]), ds_ece=float(tail["ECE_t"]))
+    ds = {k: np.asarray(v, dtype=np.float64) for k, v in ds.items()}
     srt = -np.sort(-label_probs, axis=1)
     np.savez(os.path.join(OUT, name + ".npz"), kind="clsmetrics", rows=rows, n_z=n_z, C=C, scale_T=np.float64(scale_T),
              ci_range=np.asarray(ci, dtype=np.float64), alpha=np.float64(alpha), gen=gen, labels=labels.astype(np.int64),
@@ -444,7 +472,7 @@ def gen_cls_metrics(name, rows, n_z, C, seed, *, scale_T=1.0, ci=(2.5, 97.5), al
              ci=g("CI_by_batch_list").astype(np.float32), majority_vote=g("majority_vote_by_batch_list").astype(np.int64).reshape(-1),
              ttest_reject=g("ttest_reject_by_batch_list").astype(np.int32).reshape(-1), ttest_pair=pair.astype(np.int64),
              ttest_pvalue=np.asarray(pv, dtype=np.float64),
-             unique_top2=((srt[:, 0] > srt[:, 1]) & ((C < 3) | (srt[:, 1] > srt[:, min(2, C - 1)]))))
+             unique_top2=((srt[:, 0] > srt[:, 1]) & ((C < 3) | (srt[:, 1] > srt[:, min(2, C - 1)]))), **ds)
     print(f"{name}: rows={rows} n_z={n_z} C={C} accuracy={np.mean(g('majority_vote_by_batch_list').reshape(-1) == labels):.3f} "
           f"reject={np.mean(g('ttest_reject_by_batch_list')):.3f}")
 
