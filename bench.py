@@ -291,6 +291,22 @@ def main():
                                     "frac_executed": ach / PEAK_BF16_MATRIX_TFLOPS, "traffic": None,
                                     "algorithmic_fp32_tflops": achieved,
                                     "algorithmic_over_fp32_matrix_peak": achieved / PEAK_FP32_MATRIX_TFLOPS})
+        if (world == 1 and not a.no_cpu_baseline and arith == _lib.ARITH_F32_MFMA and kind == "guided" and H == 128
+                and y_dim == 1 and N > 7 * 256 * 32):
+            # beside the headline, never instead of it: ONE more pass of the same workload through the opt-in split-bf16
+            # arithmetic (CARD_ARITH_SPLIT_BF16: fp32 operands cut exactly into three bf16 parts, six bf16 MFMAs per
+            # k-step, fp32 accumulation; same parity bar).  Not part of `value` / `ms_per_step`.
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            sampler.run(x[:256], y0[:256], y0[:256], coef, T, seed=1, n_z=a.nz, arith=_lib.ARITH_SPLIT_BF16)   # warm-up
+            s0.record()
+            ys = sampler.run(x, y0, y0, coef, T, seed=4321, elem_offset=elem_offset, n_z=a.nz, arith=_lib.ARITH_SPLIT_BF16)
+            s1.record()
+            torch.cuda.synchronize()
+            ms = s0.elapsed_time(s1)
+            out["opt_in_split_bf16"] = {"value": float(N) * T / (ms * 1e-3), "unit": "sample-steps/s", "ms_per_step": ms,
+                                        "finite": bool(torch.isfinite(ys).all()), "kernel": "card_sample_split_kernel",
+                                        "note": "opt-in arithmetic (card_run_args.arith = CARD_ARITH_SPLIT_BF16), fp32 accuracy on "
+                                                "the bf16 matrix pipe; the headline above is FP32 MFMA as north_star specifies"}
         if world == 1 and not a.no_cpu_baseline:
             threads = torch.get_num_threads()
             from oracle import card_oracle as orc
