@@ -26,6 +26,7 @@ constexpr int kWaves = 4;
 constexpr int kThreads = kWaves * 64;
 constexpr int kTileM = 32;
 constexpr int kCmax = 32;          // classes, padded
+constexpr int kCsmall = 16;        // up to here lin4 runs on the four-block 16 x 16 x 1 MFMA
 constexpr int kExLd = kF + 4;      // activation exchange row stride (floats)
 constexpr int kYLd = kCmax + 4;    // ys / partial-tile row stride
 constexpr int kGRow = 3 * kF;
@@ -366,7 +367,8 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
                 if (q < p.nq1) {
                     const f32x4 yb = lds4(ysr[g] + 8 * q);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[4 * q + e], yb[e], acc, 0, 0, 0);
+                    for (int e = 0; e < 4; ++e)              // k-step (q, e) holds classes 8q + e and 8q + 4 + e: skip all-padding ones
+                        if (8 * q + e < C) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[4 * q + e], yb[e], acc, 0, 0, 0);
                 }
             }
             epilogue_bn(acc, gl[g] + 32 * w, ts);
@@ -395,12 +397,25 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
             f32x16 part;
 #pragma unroll
             for (int r = 0; r < 16; ++r) part[r] = 0.0f;
+            if (C <= kCsmall) {
+                // Up to 16 classes: v_mfma_f32_16x16x1_4b_f32, four independent 16-class x 16-chain x 1 blocks in half the
+                // matrix-pipe time of a 32 x 32 x 2 (32 cycles; tools/ubench/mfma4b.hip).  Block b = lane >> 4 takes, from
+                // the same accumulator register, chains 16 (b & 1) .. + 15 and the feature of lane half b >> 1; the
+                // result register 4b + i of a lane is class 4 (lane >> 4) + i of chain 16 (b & 1) + (lane & 15).  Blocks b
+                // and b + 2 are the two feature halves of one chain group and are added here.
 #pragma unroll
-            for (int r = 0; r < 16; ++r) part = __builtin_amdgcn_mfma_f32_32x32x2f32(A4[r], acc[r], part, 0, 0, 0);
+                for (int r = 0; r < 16; ++r) part = __builtin_amdgcn_mfma_f32_16x16x1f32(A4[r], acc[r], part, 0, 0, 0);
+                float* const rd = red[g] + (w * kTileM + (lane & 15)) * kYLd + 4 * (lane >> 4);
+                *reinterpret_cast<f32x4*>(rd) = f32x4{part[0] + part[8], part[1] + part[9], part[2] + part[10], part[3] + part[11]};
+                *reinterpret_cast<f32x4*>(rd + 16 * kYLd) = f32x4{part[4] + part[12], part[5] + part[13], part[6] + part[14], part[7] + part[15]};
+            } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<f32x4*>(red[g] + (w * kTileM + m) * kYLd + 8 * q + 4 * hh) =
-                    f32x4{part[4 * q + 0], part[4 * q + 1], part[4 * q + 2], part[4 * q + 3]};
+                for (int r = 0; r < 16; ++r) part = __builtin_amdgcn_mfma_f32_32x32x2f32(A4[r], acc[r], part, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<f32x4*>(red[g] + (w * kTileM + m) * kYLd + 8 * q + 4 * hh) =
+                        f32x4{part[4 * q + 0], part[4 * q + 1], part[4 * q + 2], part[4 * q + 3]};
+            }
         }
         PROF_T(5);
         __syncthreads();
@@ -489,7 +504,8 @@ __global__ void cls_pack_head_kernel(const float* __restrict__ W4, int C, float*
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= kWaves * 4 * 256) return;
     const int e = idx & 3, l = (idx >> 2) & 63, q = (idx >> 8) & 3, j = idx >> 10;
-    const int cls = l & 31;
+    // C <= kCsmall: the four-block 16 x 16 x 1 form, A[block = l >> 4][class = l & 15] with the feature half of block >> 1 = l >> 5
+    const int cls = C <= kCsmall ? (l & 15) : (l & 31);
     out[idx] = cls < C ? W4[cls * kF + 32 * j + 8 * q + 4 * (l >> 5) + e] * kLn2 : 0.0f;
 }
 
