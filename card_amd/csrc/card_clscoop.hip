@@ -10,7 +10,8 @@
 //     wave's 32 features of x_feat (registers, loaded once per tile)
 //   * layers 2, 3 as in the regression kernel (activation exchange through a chain-major LDS tile)
 //   * lin4 on MFMA too: the accumulators of layer 3 are, register for register, the B operand of a 32-class x 32-chain
-//     tile with K = this wave's 32 features; the four waves' partial tiles are exchanged through LDS and added in wave
+//     tile with K = this wave's 32 features (up to 16 classes: of four 16-class x 16-chain blocks of the four-block
+//     16 x 16 x 1 MFMA, half the matrix-pipe time); the four waves' partial tiles are exchanged through LDS and added in wave
 //     order; wave w then updates classes [8w, 8w+8) of every chain (posterior update in the reference's fp32 order,
 //     noise per (chain, class) element) and writes them back to ys
 // Eval-mode BatchNorm is the per-feature affine folded into the gamma table (scale) and a shift table; softplus runs in
