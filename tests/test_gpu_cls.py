@@ -257,10 +257,11 @@ def test_f128_cooperative_kernel_equals_gemm_backend_in_rng_mode(monkeypatch):
         assert err <= TOL
 
 
-@pytest.mark.parametrize("F,C", [(128, 10), (128, 32), (128, 5), (256, 10)])
+@pytest.mark.parametrize("F,C", [(128, 10), (128, 32), (128, 5), (256, 10), (128, 1), (128, 8), (128, 9), (128, 16), (128, 17)])
 def test_cls_without_guidance_and_class_count_edges(F, C):
     """ConditionalModel(guidance=False) (classification/model.py:31: lin1 sees y_t alone) and class counts at the
-    edges of the cooperative kernel's 8-class groups, against the oracle on seeded weights."""
+    edges of the cooperative kernel's 8-class groups and of its two lin4 forms (four-block 16 x 16 x 1 MFMA up to 16
+    classes, 32 x 32 x 2 above), against the oracle on seeded weights."""
     T, N = 8, 70
     alphas, _, omabs = orc.make_schedule("linear", T, 1e-4, 0.3)
     coef = cuda(make_coef_table(alphas, omabs))
