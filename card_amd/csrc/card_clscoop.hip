@@ -37,7 +37,8 @@ constexpr int kExBuf = kWaves * kTileM * kYLd;        // one activation exchange
                                                       // lin4 partial tiles [4][32][36] (written after layer 2 has read the buffer,
                                                       // read before layer 1 writes it again)
 constexpr int kC1Floats = kF * kTileM;                // hoisted layer-1 tile, [wave][q][lane][4]
-constexpr int kTileLdsFloats = 2 * kExBuf + kTileM * kYLd + 2 * kGRow + kZFloats + kC1Floats;   // per tile position
+constexpr int kExBuf1 = kTileM * kExLd;              // the second exchange buffer has no alias: [32][132] only
+constexpr int kTileLdsFloats = kExBuf + kExBuf1 + kTileM * kYLd + 2 * kGRow + kZFloats + kC1Floats;   // per tile position
 constexpr int kGmax = 2;                             // tile positions per workgroup
 constexpr long long kChunkTiles = 8192;              // tiles per sliced chunk: bounds the hand-over buffer (262 144 chains)
 __host__ __device__ constexpr int lds_floats(int G) { return G * kTileLdsFloats + kTab; }
@@ -110,10 +111,17 @@ __device__ __forceinline__ void epilogue_bn(f32x16& acc, const float* gl, const 
     __builtin_amdgcn_s_setprio(kPrioMfma);
 }
 
-// One workgroup = four waves (one per SIMD, up to 512 registers each) that advance G tiles in lockstep with ONE copy of
-// the weight fragments in registers.  G = 2 is what keeps a CU's matrix pipes busy: while the waves wait at a barrier
-// for one tile's exchange, there is nothing else to run (a second workgroup does not fit: 2 x 128 weight registers
-// per lane), so the second tile's work between the same barriers halves the barrier stalls per tile-timestep.
+// One workgroup = four waves (one per SIMD) that advance G tiles in lockstep with ONE copy of the weight fragments in
+// registers.  Two tile positions per CU keep its matrix pipes busy through the barriers and LDS waits of a tile; two forms:
+//   * PAIR (default): two one-tile workgroups per CU (G = 1, __launch_bounds__(256, 2): 256 registers per wave, two waves
+//     per SIMD).  The 128 W2 / W3 fragment registers leave 128 for everything else, so the lin1 and lin4 fragments are not
+//     held: they are re-read from L2 where they are used (two + four 16-byte loads per lane and timestep, covered by the other
+//     wave of the SIMD), and the Philox block keeps ~29 values in scratch.  The hardware interleaves the two waves of a
+//     SIMD instruction by instruction: every LDS wait, barrier and MFMA -> VALU dependency of one tile is filled with the
+//     other tile's work.  17.6 vs 20.0 us per timestep for the reference's MNIST test minibatch (A/B in one box).
+//   * CARD_AMD_CLSCOOP_FORM=two (round 2's first form, kept for A/B): ONE workgroup of up to 512 registers per wave that
+//     advances G = 2 tiles in its one instruction stream; a wave issues in order, so the second tile fills the first
+//     one's waits only as far as the compiler interleaves the two by hand.
 //
 // Time slicing.  A tile is NOT tied to a workgroup for the whole loop: the timesteps of a call are cut into n_seg
 // segments and the (tile, segment) pairs are laid out as slots q = segment * n_tiles + tile; one launch ("slice") runs
@@ -122,8 +130,8 @@ __device__ __forceinline__ void epilogue_bn(f32x16& acc, const float* gl, const 
 // segments land in different slices in order (n_tiles >= slots per slice when slicing is on), stream order is the only
 // synchronisation, and a chain's state travels through ybuf.  The arithmetic per chain and timestep does not depend
 // on G or on the slicing: results are bit-identical to the one-tile, un-sliced form.
-template <int G>
-__global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const ClsCoopParams p) {
+template <int G, bool PAIR = false>
+__global__ __launch_bounds__(kThreads, PAIR ? 2 : 1) void card_sample_cls_coop_kernel(const ClsCoopParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int kTileLds = kTileLdsFloats;
     float* const tab = lds + G * kTileLds;
@@ -145,9 +153,11 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        if (q < p.nq1) a = *reinterpret_cast<const f32x4*>(p.w1f + ((w * p.nq1 + q) * 64 + lane) * 4);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(p.w4f + ((w * 4 + q) * 64 + lane) * 4);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (!PAIR) {                                         // PAIR: re-read from L2 where they are used (256 registers per wave)
+            if (q < p.nq1) a = *reinterpret_cast<const f32x4*>(p.w1f + ((w * p.nq1 + q) * 64 + lane) * 4);
+            b = *reinterpret_cast<const f32x4*>(p.w4f + ((w * 4 + q) * 64 + lane) * 4);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) { A1[4 * q + e] = a[e]; A4[4 * q + e] = b[e]; }
     }
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
     for (int g = 0; g < G; ++g) {
         float* base = lds + g * kTileLds;
         ex[g] = base;                                        // 2 x [32][132] activations
-        ys[g] = ex[g] + 2 * kExBuf;                          // [32][36] y_t, chain-major
+        ys[g] = ex[g] + kExBuf + kExBuf1;                    // [32][36] y_t, chain-major
         red[g] = ex[g];                                      // [4][32][36] lin4 partial tiles: alias of exchange buffer 0
         gsl[g] = ys[g] + kTileM * kYLd;                      // 2 gamma rows
         zbuf[g] = gsl[g] + 2 * kGRow;                        // [4][32][36] normals of the current draw block
@@ -367,9 +377,11 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
             for (int q = 0; q < 4; ++q) {
                 if (q < p.nq1) {
                     const f32x4 yb = lds4(ysr[g] + 8 * q);
+                    f32x4 a1 = {A1[4 * q + 0], A1[4 * q + 1], A1[4 * q + 2], A1[4 * q + 3]};
+                    if (PAIR) a1 = *reinterpret_cast<const f32x4*>(p.w1f + ((w * p.nq1 + q) * 64 + lane) * 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)              // k-step (q, e) holds classes 8q + e and 8q + 4 + e: skip all-padding ones
-                        if (8 * q + e < C) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[4 * q + e], yb[e], acc, 0, 0, 0);
+                        if (8 * q + e < C) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], yb[e], acc, 0, 0, 0);
                 }
             }
             epilogue_bn(acc, gl[g] + 32 * w, ts);
@@ -398,6 +410,14 @@ __global__ __launch_bounds__(kThreads) void card_sample_cls_coop_kernel(const Cl
             f32x16 part;
 #pragma unroll
             for (int r = 0; r < 16; ++r) part[r] = 0.0f;
+            if (PAIR) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(p.w4f + ((w * 4 + q) * 64 + lane) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) A4[4 * q + e] = b[e];
+                }
+            }
             if (C <= kCsmall) {
                 // Up to 16 classes: v_mfma_f32_16x16x1_4b_f32, four independent 16-class x 16-chain x 1 blocks in half the
                 // matrix-pipe time of a 32 x 32 x 2 (32 cycles; tools/ubench/mfma4b.hip).  Block b = lane >> 4 takes, from
@@ -547,6 +567,7 @@ int clscoop_create(card_sampler* s, const card_model_desc* d, hipStream_t stream
     s->lds_bytes = (size_t)lds_floats(kGmax) * sizeof(float);
     HIP_TRY(hipFuncSetAttribute((const void*)card_sample_cls_coop_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats(1) * sizeof(float))));
     HIP_TRY(hipFuncSetAttribute((const void*)card_sample_cls_coop_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats(2) * sizeof(float))));
+    HIP_TRY(hipFuncSetAttribute((const void*)card_sample_cls_coop_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats(1) * sizeof(float))));
     s->coop_blocks = 1;
     cls_pack_hidden_kernel<<<kF * kF / 256, 256, 0, stream>>>(d->W[1], s->wpk);
     cls_pack_hidden_kernel<<<kF * kF / 256, 256, 0, stream>>>(d->W[2], s->wpk + kF * kF);
@@ -588,7 +609,17 @@ int clscoop_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     const bool slicing = !(sv && sv[0] == '0');
     const long long P = (long long)s->num_cu * G;               // slots one launch runs
     const int n_steps = r.t_hi - r.t_lo + 1;
+    // Two tile positions per CU: as TWO one-tile workgroups (PAIR form, the default: two waves per SIMD, the hardware
+    // interleaves them) or, CARD_AMD_CLSCOOP_FORM=two (A/B), as one workgroup that advances two tiles in its one instruction stream
+    const char* fv = getenv("CARD_AMD_CLSCOOP_FORM");
+    const bool pair = !(fv && fv[0] == 't') && G == 2;
     auto launch = [&](int g_eff, long long grid) -> int {
+        if (pair && g_eff == 2) {
+            p.g_eff = 1;
+            card_sample_cls_coop_kernel<1, true><<<dim3((unsigned)(p.q1 - p.q0)), dim3(kThreads), lds_floats(1) * sizeof(float), stream>>>(p);
+            HIP_TRY(hipGetLastError());
+            return CARD_OK;
+        }
         p.g_eff = g_eff;
         if (g_eff == 1) card_sample_cls_coop_kernel<1><<<dim3((unsigned)grid), dim3(kThreads), lds_floats(1) * sizeof(float), stream>>>(p);
         else card_sample_cls_coop_kernel<2><<<dim3((unsigned)grid), dim3(kThreads), lds_floats(2) * sizeof(float), stream>>>(p);

@@ -319,9 +319,11 @@ def test_bn_model_in_train_mode_is_refused():
 
 @pytest.mark.parametrize("rows,n_z,C", [(250, 100, 10), (173, 97, 3), (40, 100, 10)])
 def test_f128_time_sliced_two_tile_form_is_bit_identical(rows, n_z, C, monkeypatch, f128_kernel):
-    """card_clscoop.hip: workgroups advancing two tiles at once and the round-robin time slicing (782 tiles = the MNIST
-    test minibatch of 250 images x 100 z, classification/configs/mnist.yml) against the plain form (one tile per
-    workgroup, whole loops): same bits in every output mode, also through the entry point that allocates nothing."""
+    """card_clscoop.hip: two tile positions per CU -- as two one-tile workgroups at 256 registers per wave (the default
+    "pair" form) or as one workgroup advancing two tiles (CARD_AMD_CLSCOOP_FORM=two) -- and the round-robin time slicing
+    (782 tiles = the MNIST test minibatch of 250 images x 100 z, classification/configs/mnist.yml) against the plain form
+    (one tile per workgroup, whole loops): same bits in every output mode, also through the entry point that allocates
+    nothing."""
     if f128_kernel != "coop":
         pytest.skip("cooperative kernel only")
     T = 130
@@ -332,9 +334,11 @@ def test_f128_time_sliced_two_tile_form_is_bit_identical(rows, n_z, C, monkeypat
     alphas, _, omabs = orc.make_schedule("linear", T, 1e-4, 0.1)
     coef = cuda(make_coef_table(alphas, omabs))
     outs = {}
-    for name, g, sl in (("sliced2", "2", "1"), ("plain1", "1", "0"), ("sliced1", "1", "1"), ("plain2", "2", "0")):
+    for name, g, sl, form in (("sliced2", "2", "1", "pair"), ("plain1", "1", "0", "pair"), ("sliced1", "1", "1", "pair"),
+                              ("plain2", "2", "0", "pair"), ("sliced2_two", "2", "1", "two"), ("plain2_two", "2", "0", "two")):
         monkeypatch.setenv("CARD_AMD_CLSCOOP_G", g)
         monkeypatch.setenv("CARD_AMD_CLSCOOP_SLICE", sl)
+        monkeypatch.setenv("CARD_AMD_CLSCOOP_FORM", form)
         s = Sampler.from_cls_state_dict(sd, device=DEV)
         last = s.run(xf, y0, y0, coef, T, seed=12, elem_offset=3, n_z=n_z)
         sel = s.run(xf, y0, y0, coef, T, seed=12, elem_offset=3, n_z=n_z, out_mode=_lib.OUT_SELECT, states=[0, 1, 64, 65, T])
@@ -342,7 +346,7 @@ def test_f128_time_sliced_two_tile_form_is_bit_identical(rows, n_z, C, monkeypat
         outs[name] = (last, sel, seg)
         if name == "sliced2":
             assert torch.equal(s.run(xf, y0, y0, coef, T, seed=12, elem_offset=3, n_z=n_z, static_scratch=True), last)
-    for name in ("plain1", "sliced1", "plain2"):
+    for name in ("plain1", "sliced1", "plain2", "sliced2_two", "plain2_two"):
         for a, b in zip(outs["sliced2"], outs[name]):
             assert torch.equal(a, b) and torch.isfinite(a).all(), name
     assert torch.equal(outs["sliced2"][0], outs["sliced2"][1][-1])
@@ -350,6 +354,7 @@ def test_f128_time_sliced_two_tile_form_is_bit_identical(rows, n_z, C, monkeypat
     w = orc.ClsWeights.from_state_dict(sd, guidance=True)
     monkeypatch.setenv("CARD_AMD_CLSCOOP_G", "2")
     monkeypatch.setenv("CARD_AMD_CLSCOOP_SLICE", "1")
+    monkeypatch.setenv("CARD_AMD_CLSCOOP_FORM", "pair")
     s = Sampler.from_cls_state_dict(sd, device=DEV)
     N = rows * n_z
     noise = torch.randn(T, N, C, generator=gen)
