@@ -434,3 +434,41 @@ def test_imagenet_head_at_its_real_dimensions_against_oracle(F, C):
     a = s.run(cuda(xf[:3]), cuda(y0[:3]), cuda(y0[:3]), coef, T, seed=7, n_z=9)
     b = s.run(cuda(xf[:3].repeat_interleave(9, 0)), cuda(y0[:3].repeat_interleave(9, 0)), cuda(y0[:3].repeat_interleave(9, 0)), coef, T, seed=7)
     assert torch.equal(a, b) and torch.isfinite(a).all()
+
+
+@pytest.mark.parametrize("C", [1, 9, 16, 17, 32])
+def test_f128_two_workgroups_per_cu_form_over_class_counts(C, monkeypatch):
+    """The default form above one tile per CU (two one-tile workgroups per CU at 256 registers per wave, lin1 / lin4
+    fragments re-read from L2) at class counts on both sides of the 8-class groups and of the two lin4 forms: same bits
+    as the one-workgroup-per-CU form and as the two-tile workgroup, in RNG mode and for eps_theta, and <= 1e-4 from the
+    oracle under injected noise on the chains of the first and the last input row."""
+    T, rows, n_z = 12, 90, 100                               # 9 000 chains = 282 tiles > 256 CUs
+    sd = cls_state_dict(128, C, T, 11)
+    gen = torch.Generator().manual_seed(C)
+    xf = cuda(torch.randn(rows, 128, generator=gen))
+    y0 = cuda(torch.softmax(torch.randn(rows, C, generator=gen) * 2, 1))
+    alphas, _, omabs = orc.make_schedule("linear", T, 1e-4, 0.3)
+    coef = cuda(make_coef_table(alphas, omabs))
+    outs = {}
+    for name, g, form in (("pair", "2", "pair"), ("single", "1", "pair"), ("two", "2", "two")):
+        monkeypatch.setenv("CARD_AMD_CLSCOOP_G", g)
+        monkeypatch.setenv("CARD_AMD_CLSCOOP_FORM", form)
+        s = Sampler.from_cls_state_dict(sd, device=DEV)
+        outs[name] = (s.run(xf, y0, y0, coef, T, seed=5, elem_offset=7, n_z=n_z, out_mode=_lib.OUT_ALL),
+                      s.eps_theta(xf.repeat_interleave(n_z, 0), y0.repeat_interleave(n_z, 0), y0.repeat_interleave(n_z, 0), 4))
+    for name in ("single", "two"):
+        assert torch.equal(outs["pair"][0], outs[name][0]) and torch.equal(outs["pair"][1], outs[name][1]), name
+    assert torch.isfinite(outs["pair"][0]).all()
+    monkeypatch.setenv("CARD_AMD_CLSCOOP_G", "2")
+    monkeypatch.setenv("CARD_AMD_CLSCOOP_FORM", "pair")
+    s = Sampler.from_cls_state_dict(sd, device=DEV)
+    w = orc.ClsWeights.from_state_dict(sd, guidance=True)
+    N = rows * n_z
+    noise = torch.randn(T, N, C, generator=gen)
+    got = s.run(xf, y0, y0, coef, T, noise=cuda(noise), n_z=n_z, out_mode=_lib.OUT_ALL).cpu()
+    for r in (0, rows - 1):
+        sl_ = slice(r * n_z, r * n_z + 20)
+        tile = lambda t: t[r:r + 1].cpu().repeat(20, 1)
+        want = torch.stack(orc.p_sample_loop(w, tile(xf), tile(y0), tile(y0), T, alphas, omabs, noise[:, sl_]), 0)
+        worst = max(norm_rel_err(got[k][sl_], want[k]) for k in range(T + 1))
+        assert worst <= TOL, (C, r, worst)
