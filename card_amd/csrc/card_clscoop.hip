@@ -39,9 +39,25 @@ constexpr int kExBuf = kWaves * kTileM * kYLd;        // one activation exchange
 constexpr int kC1Floats = kF * kTileM;                // hoisted layer-1 tile, [wave][q][lane][4]
 constexpr int kExBuf1 = kTileM * kExLd;              // the second exchange buffer has no alias: [32][132] only
 constexpr int kTileLdsFloats = kExBuf + kExBuf1 + kTileM * kYLd + 2 * kGRow + kZFloats + kC1Floats;   // per tile position
+// LDS layout of a tile position per kernel form.  FORM 0: one workgroup per CU (one or two tiles), FORM 1: PAIR, FORM 2:
+// PAIR compact (up to kCsmall classes, n_z >= 32): 20-float row pitch for y_t, the noise block and the lin4 partial tiles
+// (16 classes + 4: conflict-free for 16 lanes of a b128 access), the hoisted layer-1 tile as the two columns of the at
+// most two images a 32-chain tile spans, and with the 23 KB that frees the lin1 / lin4 fragments of the four waves.
+constexpr int kC1Ld = kF + 8;                          // row pitch of the two-column hoisted layer-1 tile
+template <int FORM> struct ClsLds {
+    static constexpr bool compact = FORM == 2;
+    static constexpr int YL = compact ? kCsmall + 4 : kYLd;
+    static constexpr int EX0 = compact ? kExBuf1 : kExBuf;      // compact: the alias [4][32][20] fits the plain buffer
+    static constexpr int Z = 4 * kTileM * YL;
+    static constexpr int C1 = compact ? 2 * kC1Ld : kC1Floats;
+    static constexpr int FR1 = compact ? kWaves * 2 * 256 : 0;  // lin1 fragments, nq1 <= 2: [wave][q][lane][4]
+    static constexpr int FR4 = compact ? kWaves * 4 * 256 : 0;  // lin4 fragments: [wave][q][lane][4]
+    static constexpr int tile = EX0 + kExBuf1 + kTileM * YL + 2 * kGRow + Z + C1 + FR1 + FR4;
+};
+static_assert(ClsLds<0>::tile == kTileLdsFloats && ClsLds<1>::tile == kTileLdsFloats, "plain layout");
 constexpr int kGmax = 2;                             // tile positions per workgroup
 constexpr long long kChunkTiles = 8192;              // tiles per sliced chunk: bounds the hand-over buffer (262 144 chains)
-__host__ __device__ constexpr int lds_floats(int G) { return G * kTileLdsFloats + kTab; }
+__host__ __device__ constexpr int lds_floats(int G, int form = 0) { return G * (form == 2 ? ClsLds<2>::tile : kTileLdsFloats) + kTab; }
 constexpr int kPrioValu = 3, kPrioMfma = 0;
 
 }  // namespace
@@ -130,10 +146,14 @@ __device__ __forceinline__ void epilogue_bn(f32x16& acc, const float* gl, const 
 // segments land in different slices in order (n_tiles >= slots per slice when slicing is on), stream order is the only
 // synchronisation, and a chain's state travels through ybuf.  The arithmetic per chain and timestep does not depend
 // on G or on the slicing: results are bit-identical to the one-tile, un-sliced form.
-template <int G, bool PAIR = false>
-__global__ __launch_bounds__(kThreads, PAIR ? 2 : 1) void card_sample_cls_coop_kernel(const ClsCoopParams p) {
+template <int G, int FORM = 0>
+__global__ __launch_bounds__(kThreads, FORM >= 1 ? 2 : 1) void card_sample_cls_coop_kernel(const ClsCoopParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int kTileLds = kTileLdsFloats;
+    using L = ClsLds<FORM>;
+    constexpr bool PAIR = FORM >= 1, COMPACT = FORM == 2;
+    static_assert(!PAIR || G == 1, "the PAIR forms are one-tile workgroups");
+    constexpr int kTileLds = L::tile, YL = L::YL, EX0 = L::EX0;
+    constexpr int kC1q = COMPACT ? 8 : 256;                 // distance between a lane's four quads of the hoisted layer-1 tile
     float* const tab = lds + G * kTileLds;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -161,11 +181,22 @@ __global__ __launch_bounds__(kThreads, PAIR ? 2 : 1) void card_sample_cls_coop_k
 #pragma unroll
         for (int e = 0; e < 4; ++e) { A1[4 * q + e] = a[e]; A4[4 * q + e] = b[e]; }
     }
+    // COMPACT: this lane's lin1 / lin4 fragments live in LDS (each lane reads back only its own slots: no barrier needed)
+    float* const fr1 = lds + L::EX0 + kExBuf1 + kTileM * YL + 2 * kGRow + L::Z + L::C1 + (w * 2 * 64 + lane) * 4;   // + q * 256
+    float* const fr4 = lds + L::EX0 + kExBuf1 + kTileM * YL + 2 * kGRow + L::Z + L::C1 + L::FR1 + (w * 4 * 64 + lane) * 4;
+    if (COMPACT) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q < 2 && q < p.nq1) *reinterpret_cast<f32x4*>(fr1 + q * 256) = *reinterpret_cast<const f32x4*>(p.w1f + ((w * p.nq1 + q) * 64 + lane) * 4);
+            *reinterpret_cast<f32x4*>(fr4 + q * 256) = *reinterpret_cast<const f32x4*>(p.w4f + ((w * 4 + q) * 64 + lane) * 4);
+        }
+    }
     __syncthreads();
     const float* const tb = tab + 32 * w + 4 * hh;                      // bias of this wave's features: + layer*128 + 8q
     const float* const ts = tab + 3 * kF + 32 * w + 4 * hh;             // shift
     const int c0 = 8 * w + 4 * hh;                                       // first of the 4 classes this lane updates
     const f32x4 b4v = lds4(tab + 6 * kF + c0);
+    const bool ys_owner = !COMPACT || c0 < kCsmall;                      // COMPACT rows hold 16 classes: waves 2, 3 own none of them
 
     const long long n_tiles = (p.n_end - p.n_begin + kTileM - 1) / kTileM;
     const int T = p.T;
@@ -188,15 +219,15 @@ __global__ __launch_bounds__(kThreads, PAIR ? 2 : 1) void card_sample_cls_coop_k
     for (int g = 0; g < G; ++g) {
         float* base = lds + g * kTileLds;
         ex[g] = base;                                        // 2 x [32][132] activations
-        ys[g] = ex[g] + kExBuf + kExBuf1;                    // [32][36] y_t, chain-major
+        ys[g] = ex[g] + EX0 + kExBuf1;                       // [32][YL] y_t, chain-major
         red[g] = ex[g];                                      // [4][32][36] lin4 partial tiles: alias of exchange buffer 0
-        gsl[g] = ys[g] + kTileM * kYLd;                      // 2 gamma rows
+        gsl[g] = ys[g] + kTileM * YL;                        // 2 gamma rows
         zbuf[g] = gsl[g] + 2 * kGRow;                        // [4][32][36] normals of the current draw block
-        c1l[g] = zbuf[g] + kZFloats + (w * 4 * 64 + lane) * 4;   // this lane's 16 values of the hoisted layer-1 tile: + q * 256
+        c1l[g] = zbuf[g] + L::Z + (w * 4 * 64 + lane) * 4;   // this lane's 16 values of the hoisted layer-1 tile: + q * 256 (COMPACT: set in the prologue)
         exw[g] = ex[g] + m * kExLd + 32 * w + 4 * hh;
         exr[g] = ex[g] + m * kExLd + 4 * hh;
-        ysw[g] = ys[g] + m * kYLd + c0;
-        ysr[g] = ys[g] + m * kYLd + 4 * hh;
+        ysw[g] = ys[g] + m * YL + c0;
+        ysr[g] = ys[g] + m * YL + 4 * hh;
         const long long q = p.q0 + (long long)blockIdx.x * p.g_eff + g;
         active[g] = g < p.g_eff && q < p.q1;
         const long long tile = active[g] ? q % n_tiles : 0;
@@ -233,9 +264,9 @@ __global__ __launch_bounds__(kThreads, PAIR ? 2 : 1) void card_sample_cls_coop_k
                 re = re < p.n_end ? re : p.n_end - 1;
                 float z4[4];
                 philox_normal4(p.seed, p.elem_offset + (unsigned long long)(re * C + cls), blk, z4);
-                float* zb = zbuf[g] + chain * kYLd + cls;
+                float* zb = zbuf[g] + chain * YL + cls;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) zb[k * kTileM * kYLd] = z4[k];
+                for (int k = 0; k < 4; ++k) zb[k * kTileM * YL] = z4[k];
             }
         }
     };
@@ -280,9 +311,17 @@ __global__ __launch_bounds__(kThreads, PAIR ? 2 : 1) void card_sample_cls_coop_k
                 }
             }
         }
+        if (COMPACT) {
+            // the tile's chains come from at most two input rows (n_z >= 32, checked by the host): one column per row;
+            // the lanes of a row write the same values to the same place
+            long long r0 = row[g] - m;
+            r0 = r0 < p.n_end ? r0 : p.n_end - 1;
+            const int sel = (int)(rr[g] - r0 / p.n_z);
+            c1l[g] = zbuf[g] + L::Z + sel * kC1Ld + 32 * w + 4 * hh;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<f32x4*>(c1l[g] + q * 256) = f32x4{c1[4 * q + 0], c1[4 * q + 1], c1[4 * q + 2], c1[4 * q + 3]};
+            *reinterpret_cast<f32x4*>(c1l[g] + q * kC1q) = f32x4{c1[4 * q + 0], c1[4 * q + 1], c1[4 * q + 2], c1[4 * q + 3]};
 #pragma unroll
         for (int k = 0; k < 4; ++k) mu[g][k] = c0 + k < C ? p.ytmean[rr[g] * C + c0 + k] : 0.0f;
         if (!first_seg[g]) {
@@ -297,13 +336,13 @@ __global__ __launch_bounds__(kThreads, PAIR ? 2 : 1) void card_sample_cls_coop_k
 #pragma unroll
                 for (int k = 0; k < 4; ++k) z[k] = c0 + k < C ? p.noise[rc[g] * C + c0 + k] : 0.0f;
             } else {
-                z = lds4(zbuf[g] + m * kYLd + c0);
+                z = lds4(zbuf[g] + m * YL + c0);
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) yv[g][k] = c0 + k < C ? z[k] + mu[g][k] : 0.0f;       // classification/diffusion_utils.py:123-124
             store_state(g, 0);
         }
-        *reinterpret_cast<f32x4*>(ysw[g]) = f32x4{yv[g][0], yv[g][1], yv[g][2], yv[g][3]};
+        if (ys_owner) *reinterpret_cast<f32x4*>(ysw[g]) = f32x4{yv[g][0], yv[g][1], yv[g][2], yv[g][3]};
         for (int i = tid; i < kGRow; i += kThreads) gsl[g][i] = p.gtab[(long long)th[g] * kGRow + i];
     }
     __syncthreads();
@@ -311,7 +350,7 @@ __global__ __launch_bounds__(kThreads, PAIR ? 2 : 1) void card_sample_cls_coop_k
     auto publish = [&](int g, const f32x16& a, int buf) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<f32x4*>(exw[g] + buf * kExBuf + 8 * q) = f32x4{a[4 * q + 0], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+            *reinterpret_cast<f32x4*>(exw[g] + buf * EX0 + 8 * q) = f32x4{a[4 * q + 0], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
     };
     auto hidden = [&](int g, const float (&A)[64], int buf, int layer, const float* gl) -> f32x16 {
         f32x16 acc;
@@ -322,7 +361,7 @@ __global__ __launch_bounds__(kThreads, PAIR ? 2 : 1) void card_sample_cls_coop_k
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const f32x4 h = lds4(exr[g] + buf * kExBuf + 32 * (i >> 2) + 8 * (i & 3));
+            const f32x4 h = lds4(exr[g] + buf * EX0 + 32 * (i >> 2) + 8 * (i & 3));
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * i + e], h[e], acc, 0, 0, 0);
         }
@@ -370,7 +409,7 @@ __global__ __launch_bounds__(kThreads, PAIR ? 2 : 1) void card_sample_cls_coop_k
             f32x16 acc;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 v = lds4(c1l[g] + q * 256);
+                const f32x4 v = lds4(c1l[g] + q * kC1q);
                 acc[4 * q + 0] = v[0]; acc[4 * q + 1] = v[1]; acc[4 * q + 2] = v[2]; acc[4 * q + 3] = v[3];
             }
 #pragma unroll
@@ -378,7 +417,8 @@ __global__ __launch_bounds__(kThreads, PAIR ? 2 : 1) void card_sample_cls_coop_k
                 if (q < p.nq1) {
                     const f32x4 yb = lds4(ysr[g] + 8 * q);
                     f32x4 a1 = {A1[4 * q + 0], A1[4 * q + 1], A1[4 * q + 2], A1[4 * q + 3]};
-                    if (PAIR) a1 = *reinterpret_cast<const f32x4*>(p.w1f + ((w * p.nq1 + q) * 64 + lane) * 4);
+                    if (COMPACT) a1 = lds4(fr1 + (q & 1) * 256);
+                    else if (PAIR) a1 = *reinterpret_cast<const f32x4*>(p.w1f + ((w * p.nq1 + q) * 64 + lane) * 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)              // k-step (q, e) holds classes 8q + e and 8q + 4 + e: skip all-padding ones
                         if (8 * q + e < C) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], yb[e], acc, 0, 0, 0);
@@ -413,7 +453,7 @@ __global__ __launch_bounds__(kThreads, PAIR ? 2 : 1) void card_sample_cls_coop_k
             if (PAIR) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(p.w4f + ((w * 4 + q) * 64 + lane) * 4);
+                    const f32x4 b = COMPACT ? lds4(fr4 + q * 256) : *reinterpret_cast<const f32x4*>(p.w4f + ((w * 4 + q) * 64 + lane) * 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) A4[4 * q + e] = b[e];
                 }
@@ -426,15 +466,15 @@ __global__ __launch_bounds__(kThreads, PAIR ? 2 : 1) void card_sample_cls_coop_k
                 // and b + 2 are the two feature halves of one chain group and are added here.
 #pragma unroll
                 for (int r = 0; r < 16; ++r) part = __builtin_amdgcn_mfma_f32_16x16x1f32(A4[r], acc[r], part, 0, 0, 0);
-                float* const rd = red[g] + (w * kTileM + (lane & 15)) * kYLd + 4 * (lane >> 4);
+                float* const rd = red[g] + (w * kTileM + (lane & 15)) * YL + 4 * (lane >> 4);
                 *reinterpret_cast<f32x4*>(rd) = f32x4{part[0] + part[8], part[1] + part[9], part[2] + part[10], part[3] + part[11]};
-                *reinterpret_cast<f32x4*>(rd + 16 * kYLd) = f32x4{part[4] + part[12], part[5] + part[13], part[6] + part[14], part[7] + part[15]};
+                *reinterpret_cast<f32x4*>(rd + 16 * YL) = f32x4{part[4] + part[12], part[5] + part[13], part[6] + part[14], part[7] + part[15]};
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) part = __builtin_amdgcn_mfma_f32_32x32x2f32(A4[r], acc[r], part, 0, 0, 0);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<f32x4*>(red[g] + (w * kTileM + m) * kYLd + 8 * q + 4 * hh) =
+                    *reinterpret_cast<f32x4*>(red[g] + (w * kTileM + m) * YL + 8 * q + 4 * hh) =
                         f32x4{part[4 * q + 0], part[4 * q + 1], part[4 * q + 2], part[4 * q + 3]};
             }
         }
@@ -445,10 +485,10 @@ __global__ __launch_bounds__(kThreads, PAIR ? 2 : 1) void card_sample_cls_coop_k
         for (int g = 0; g < G; ++g) {
             if (!on[g]) continue;
             const int t = th[g] - it;
-            f32x4 eps = lds4(red[g] + m * kYLd + c0);
+            f32x4 eps = lds4(red[g] + m * YL + c0);
 #pragma unroll
             for (int ww = 1; ww < kWaves; ++ww) {
-                const f32x4 v = lds4(red[g] + (ww * kTileM + m) * kYLd + c0);
+                const f32x4 v = lds4(red[g] + (ww * kTileM + m) * YL + c0);
                 eps += v;
             }
             eps += b4v;
@@ -462,7 +502,7 @@ __global__ __launch_bounds__(kThreads, PAIR ? 2 : 1) void card_sample_cls_coop_k
             // posterior update per (chain, class), classification/diffusion_utils.py:80-86 (t >= 1) / :98-100 (t == 0)
             const float ci = cf[g][0], co = cf[g][1], cs = cf[g][2], g0 = cf[g][3], g1 = cf[g][4], g2 = cf[g][5], sg = cf[g][6];
             if (t >= 1 && !p.noise) {
-                const f32x4 zz = lds4(zbuf[g] + ((T - t) & 3) * kTileM * kYLd + m * kYLd + c0);
+                const f32x4 zz = lds4(zbuf[g] + ((T - t) & 3) * kTileM * YL + m * YL + c0);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) z[g][k] = zz[k];
             }
@@ -474,7 +514,7 @@ __global__ __launch_bounds__(kThreads, PAIR ? 2 : 1) void card_sample_cls_coop_k
                 yv[g][k] = c0 + k < C ? v : 0.0f;
             }
             store_state(g, T - t);
-            *reinterpret_cast<f32x4*>(ysw[g]) = f32x4{yv[g][0], yv[g][1], yv[g][2], yv[g][3]};
+            if (ys_owner) *reinterpret_cast<f32x4*>(ysw[g]) = f32x4{yv[g][0], yv[g][1], yv[g][2], yv[g][3]};
         }
         PROF_T(7);
         __syncthreads();
@@ -567,7 +607,8 @@ int clscoop_create(card_sampler* s, const card_model_desc* d, hipStream_t stream
     s->lds_bytes = (size_t)lds_floats(kGmax) * sizeof(float);
     HIP_TRY(hipFuncSetAttribute((const void*)card_sample_cls_coop_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats(1) * sizeof(float))));
     HIP_TRY(hipFuncSetAttribute((const void*)card_sample_cls_coop_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats(2) * sizeof(float))));
-    HIP_TRY(hipFuncSetAttribute((const void*)card_sample_cls_coop_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats(1) * sizeof(float))));
+    HIP_TRY(hipFuncSetAttribute((const void*)card_sample_cls_coop_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats(1) * sizeof(float))));
+    HIP_TRY(hipFuncSetAttribute((const void*)card_sample_cls_coop_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats(1, 2) * sizeof(float))));
     s->coop_blocks = 1;
     cls_pack_hidden_kernel<<<kF * kF / 256, 256, 0, stream>>>(d->W[1], s->wpk);
     cls_pack_hidden_kernel<<<kF * kF / 256, 256, 0, stream>>>(d->W[2], s->wpk + kF * kF);
@@ -613,10 +654,15 @@ int clscoop_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     // interleaves them) or, CARD_AMD_CLSCOOP_FORM=two (A/B), as one workgroup that advances two tiles in its one instruction stream
     const char* fv = getenv("CARD_AMD_CLSCOOP_FORM");
     const bool pair = !(fv && fv[0] == 't') && G == 2;
+    // compact LDS layout with the lin1 / lin4 fragments in LDS: up to 16 classes and tiles that span at most two input rows
+    // (CARD_AMD_CLSCOOP_FORM=pair1 keeps the plain PAIR layout, A/B)
+    const bool compact = pair && s->y_dim <= kCsmall && r.n_z >= kTileM && !(fv && strcmp(fv, "pair1") == 0);
     auto launch = [&](int g_eff, long long grid) -> int {
         if (pair && g_eff == 2) {
             p.g_eff = 1;
-            card_sample_cls_coop_kernel<1, true><<<dim3((unsigned)(p.q1 - p.q0)), dim3(kThreads), lds_floats(1) * sizeof(float), stream>>>(p);
+            const dim3 pgrid((unsigned)(p.q1 - p.q0));
+            if (compact) card_sample_cls_coop_kernel<1, 2><<<pgrid, dim3(kThreads), lds_floats(1, 2) * sizeof(float), stream>>>(p);
+            else card_sample_cls_coop_kernel<1, 1><<<pgrid, dim3(kThreads), lds_floats(1) * sizeof(float), stream>>>(p);
             HIP_TRY(hipGetLastError());
             return CARD_OK;
         }
