@@ -52,7 +52,8 @@ template <int FORM> struct ClsLds {
     static constexpr int C1 = compact ? 2 * kC1Ld : kC1Floats;
     static constexpr int FR1 = compact ? kWaves * 2 * 256 : 0;  // lin1 fragments, nq1 <= 2: [wave][q][lane][4]
     static constexpr int FR4 = compact ? kWaves * 4 * 256 : 0;  // lin4 fragments: [wave][q][lane][4]
-    static constexpr int tile = EX0 + kExBuf1 + kTileM * YL + 2 * kGRow + Z + C1 + FR1 + FR4;
+    static constexpr int XF = compact ? 2 * kC1Ld : 0;          // x_feat of the tile's two images
+    static constexpr int tile = EX0 + kExBuf1 + kTileM * YL + 2 * kGRow + Z + C1 + FR1 + FR4 + XF;
 };
 static_assert(ClsLds<0>::tile == kTileLdsFloats && ClsLds<1>::tile == kTileLdsFloats, "plain layout");
 constexpr int kGmax = 2;                             // tile positions per workgroup
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(kThreads, FORM >= 1 ? 2 : 1) void card_sample_cls_c
     long long row[G], rc[G], rr[G];
     int th[G], cnt[G], gcur[G];
     f32x16 xf[G];
+    float* xfl = nullptr;                                // COMPACT (G = 1): this lane's x_feat values in LDS, + 8 * q
     float yv[G][4], mu[G][4];
     uint32_t zblock[G];
     int n_iter = 0;
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(kThreads, FORM >= 1 ? 2 : 1) void card_sample_cls_c
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 c1[4 * q + k] = b[k];
-                xf[g][4 * q + k] = p.xfeat[rr[g] * kF + 32 * w + 8 * q + 4 * hh + k];
+                xf[g][4 * q + k] = p.xfeat[rr[g] * kF + 32 * w + 8 * q + 4 * hh + k];     // (COMPACT: parked in LDS below, dead after that)
             }
         }
         if (p.guidance) {
@@ -318,6 +320,10 @@ __global__ __launch_bounds__(kThreads, FORM >= 1 ? 2 : 1) void card_sample_cls_c
             r0 = r0 < p.n_end ? r0 : p.n_end - 1;
             const int sel = (int)(rr[g] - r0 / p.n_z);
             c1l[g] = zbuf[g] + L::Z + sel * kC1Ld + 32 * w + 4 * hh;
+            xfl = zbuf[g] + L::Z + L::C1 + L::FR1 + L::FR4 + sel * kC1Ld + 32 * w + 4 * hh;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<f32x4*>(xfl + 8 * q) = f32x4{xf[g][4 * q + 0], xf[g][4 * q + 1], xf[g][4 * q + 2], xf[g][4 * q + 3]};
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -425,8 +431,17 @@ __global__ __launch_bounds__(kThreads, FORM >= 1 ? 2 : 1) void card_sample_cls_c
                 }
             }
             epilogue_bn(acc, gl[g] + 32 * w, ts);
+            if (COMPACT) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] *= xf[g][r];
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 xv = lds4(xfl + 8 * q);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[4 * q + k] *= xv[k];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] *= xf[g][r];
+            }
             publish(g, acc, 0);
         }
         PROF_T(1);
