@@ -136,6 +136,9 @@ __device__ __forceinline__ void epilogue_bn(f32x16& acc, const float* gl, const 
 //     wave of the SIMD), and the Philox block keeps ~29 values in scratch.  The hardware interleaves the two waves of a
 //     SIMD instruction by instruction: every LDS wait, barrier and MFMA -> VALU dependency of one tile is filled with the
 //     other tile's work.  17.6 vs 20.0 us per timestep for the reference's MNIST test minibatch (A/B in one box).
+//   * PAIR compact (FORM 2; up to 16 classes and n_z >= 32, i.e. every F = 128 config of the reference): the LDS layout
+//     ClsLds<2> -- 20-float row pitch, the hoisted layer-1 tile and x_feat as the two columns of the two images a tile
+//     spans -- leaves room for the lin1 / lin4 fragments in LDS: no L2 re-reads, 14 values in scratch; 17.05 us.
 //   * CARD_AMD_CLSCOOP_FORM=two (round 2's first form, kept for A/B): ONE workgroup of up to 512 registers per wave that
 //     advances G = 2 tiles in its one instruction stream; a wave issues in order, so the second tile fills the first
 //     one's waits only as far as the compiler interleaves the two by hand.
