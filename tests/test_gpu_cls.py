@@ -472,3 +472,24 @@ def test_f128_two_workgroups_per_cu_form_over_class_counts(C, monkeypatch):
         want = torch.stack(orc.p_sample_loop(w, tile(xf), tile(y0), tile(y0), T, alphas, omabs, noise[:, sl_]), 0)
         worst = max(norm_rel_err(got[k][sl_], want[k]) for k in range(T + 1))
         assert worst <= TOL, (C, r, worst)
+
+
+@pytest.mark.parametrize("n_z", [31, 32, 33, 47])
+def test_f128_compact_form_at_the_edge_of_two_rows_per_tile(n_z, monkeypatch):
+    """The compact two-workgroup form keeps the hoisted layer-1 tile and x_feat as the TWO columns of the input rows a
+    32-chain tile spans, which holds from n_z = 32 on (the host selects the plain form below that): same bits as the
+    one-workgroup-per-CU form on both sides of that edge, every input row different, ragged last tile."""
+    T, rows, C = 9, 301, 10                                   # > 8 192 chains, rows * n_z not a multiple of 32
+    sd = cls_state_dict(128, C, T, 13)
+    gen = torch.Generator().manual_seed(n_z)
+    xf = cuda(torch.randn(rows, 128, generator=gen))
+    y0 = cuda(torch.softmax(torch.randn(rows, C, generator=gen) * 2, 1))
+    mu = cuda(torch.randn(rows, C, generator=gen))
+    alphas, _, omabs = orc.make_schedule("linear", T, 1e-4, 0.3)
+    coef = cuda(make_coef_table(alphas, omabs))
+    outs = []
+    for g in ("2", "1"):
+        monkeypatch.setenv("CARD_AMD_CLSCOOP_G", g)
+        s = Sampler.from_cls_state_dict(sd, device=DEV)
+        outs.append(s.run(xf, y0, mu, coef, T, seed=3, n_z=n_z, out_mode=_lib.OUT_ALL))
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
