@@ -20,7 +20,7 @@ from .diffusion_utils import (  # noqa: F401
     q_sample,
     y_0_reparam,
 )
-from .guidance import GuidanceNet, guidance_for  # noqa: F401
-from .sampler import Sampler, invalidate, sampler_for  # noqa: F401
+from .guidance import GuidanceNet, describe_guidance, guidance_for  # noqa: F401
+from .sampler import ModelDescription, Sampler, describe, invalidate, sampler_for, unwrap  # noqa: F401
 
 __version__ = "0.2.1"

@@ -8,6 +8,7 @@ arguments (`noise`, `seed`, `elem_offset`, `states`) expose the kernel's validat
 Everything here runs on the GPU through libcard_hip.so.  No fallback.
 """
 import math
+import threading
 
 import numpy as np
 import torch
@@ -100,24 +101,31 @@ class _StepCtx:
     SAME model / x / y_0_hat / y_T_mean / schedule objects; only y and t change): the sampler, the prepared inputs and two
     pre-filled card_run_args (steps t >= 1, and the t = 0 step with its own one-row table).  The caller's objects are held
     through WEAK references compared by identity -- a live object cannot share its id with another, and the entry is
-    dropped the moment one of them dies -- so the context pins none of the caller's memory (x_feat of a CIFAR-10 batch is
-    410 MB); it owns only the converted copies it had to make."""
+    emptied the moment one of them dies -- so the context pins none of the caller's memory (x_feat of a CIFAR-10 batch is
+    410 MB); it owns only the converted copies it had to make.
+    One context per THREAD (ctypes releases the GIL during the call, so two threads may sample at once); the pre-filled
+    card_run_args are templates that every call copies (152 bytes) before it writes y / out / t into them."""
     __slots__ = ("refs", "sampler", "params", "versions", "in_versions", "keep", "args", "args0", "N", "T", "seed",
                  "last_t", "fn", "__weakref__")
 
     def matches(self, objs):
+        if self.refs is None:
+            return False
         for r, o in zip(self.refs, objs):
             if (r() if r is not None else None) is not o:
                 return False
         return True
 
+    def release(self):
+        """One of the caller's objects died: let go of everything this context owns (it can never match again)."""
+        self.refs, self.keep, self.args, self.args0, self.params, self.versions = None, None, None, None, (), ()
 
-_step_ctx = None
+
+_tls = threading.local()
 
 
-def _drop_step_ctx(_dead=None):
-    global _step_ctx
-    _step_ctx = None
+def _drop_step_ctx():
+    _tls.ctx = None
 
 
 def _in_versions(x, y_0_hat, y_T_mean, omabs):
@@ -128,10 +136,9 @@ def _step_ctx_for(model, x, y_0_hat, y_T_mean, alphas, omabs, fresh):
     """The cached context of this (model, inputs, schedule) combination, or a new one.  `fresh` (first step of a loop)
     re-validates the weights by identity and content (sampler_for); later steps of the loop only compare the parameters'
     version counters (a few microseconds), which catches optimizer steps / load_state_dict / in-place edits."""
-    global _step_ctx
     import ctypes as C
     import weakref
-    c = _step_ctx
+    c = getattr(_tls, "ctx", None)
     objs = (model, x, y_0_hat, y_T_mean, alphas, omabs)
     if c is not None and not fresh and c.matches(objs) and c.in_versions == _in_versions(x, y_0_hat, y_T_mean, omabs):
         for p, v in zip(c.params, c.versions):
@@ -141,10 +148,17 @@ def _step_ctx_for(model, x, y_0_hat, y_T_mean, alphas, omabs, fresh):
             return c
     s = sampler_for(model, check_content=fresh)
     c = _StepCtx()
-    c.refs = tuple(weakref.ref(o, _drop_step_ctx) if o is not None else None for o in objs)
+    cref = weakref.ref(c)
+
+    def _dead(_, cref=cref):
+        cc = cref()
+        if cc is not None:
+            cc.release()
+
+    c.refs = tuple(weakref.ref(o, _dead) if o is not None else None for o in objs)
     c.sampler = s
-    from .sampler import _tensors
-    c.params = _tensors(model)
+    from .sampler import _tensors, core_of
+    c.params = _tensors(core_of(model))
     c.versions = [p._version for p in c.params]
     c.in_versions = _in_versions(x, y_0_hat, y_T_mean, omabs)
     y0 = s._prep(y_0_hat, s.y_dim, "y_0_hat")
@@ -174,12 +188,13 @@ def _step_ctx_for(model, x, y_0_hat, y_T_mean, alphas, omabs, fresh):
     c.args0 = filled(1, coef0)
     c.seed, c.last_t = None, -1
     c.fn = _lib.lib().card_sampler_run
-    _step_ctx = c
+    _tls.ctx = c
     return c
 
 
 def _step_run(c, a, y, t, noise, seed, elem_offset):
     s = c.sampler
+    a = _lib.RunArgs.from_buffer_copy(a)          # the context's card_run_args are templates: another thread may be inside a call with its own copy
     if not (y.dtype is torch.float32 and y.is_contiguous() and y.device == s.device and not y.requires_grad):
         y = _dev_f32(y, s.device)
     if y.dim() != 2 or y.shape[0] != c.N or y.shape[1] != s.y_dim:
@@ -248,11 +263,16 @@ def _coef_row0_on_device(omabs, device):
 
 
 def p_sample_t_1to0(model, x, y, y_0_hat, y_T_mean, one_minus_alphas_bar_sqrt):
-    """regression/diffusion_utils.py:94-104: the last step (timestep index 0), no noise."""
-    c = _step_ctx
-    alphas = c.refs[4]() if (c is not None and c.refs[4] is not None) else None
-    if c is not None and c.matches((model, x, y_0_hat, y_T_mean, alphas, one_minus_alphas_bar_sqrt)):
-        # the tail of a p_sample loop over the same objects: reuse its context (weights re-checked by version counters)
+    """regression/diffusion_utils.py:94-104: the last step (timestep index 0), no noise.
+    As the tail of a p_sample loop over the same objects (the previous call of this thread was p_sample at t = 1) it
+    reuses that loop's context, whose weights were checked by content at t = T - 1 and by version counters since.  Any
+    other call -- a standalone one, or a second one in a row -- re-validates the weights by content, which is what
+    catches the reference's EMA swap `param.data.copy_` (regression/ema.py:21) between two standalone calls."""
+    c = getattr(_tls, "ctx", None)
+    alphas = c.refs[4]() if (c is not None and c.refs is not None and c.refs[4] is not None) else None
+    tail_of_loop = (c is not None and c.args is not None and c.last_t == 1 and alphas is not None
+                    and c.matches((model, x, y_0_hat, y_T_mean, alphas, one_minus_alphas_bar_sqrt)))
+    if tail_of_loop:
         c = _step_ctx_for(model, x, y_0_hat, y_T_mean, alphas, one_minus_alphas_bar_sqrt, fresh=False)
     else:
         c = _step_ctx_for(model, x, y_0_hat, y_T_mean, None, one_minus_alphas_bar_sqrt, fresh=True)

@@ -58,45 +58,11 @@ class GuidanceNet:
     def from_module(cls, net, device=None):
         """From a DeterministicFeedForwardNeuralNetwork (its `.network` Sequential: Linear, [BatchNorm1d], LeakyReLU,
         Dropout per hidden layer, then Linear -- regression/model.py:70-79) or any Sequential of those layer types."""
-        import torch.nn as nn
-        seq = getattr(net, "network", net)
-        Ws, bs, sc, sh, slope = [], [], [], [], None
-        for m in seq.children():
-            if isinstance(m, nn.Linear):
-                Ws.append(m.weight)
-                bs.append(m.bias)
-                sc.append(None)
-                sh.append(None)
-            elif isinstance(m, nn.BatchNorm1d):
-                if m.training or not m.track_running_stats:
-                    raise CardError("f_phi BatchNorm1d must be in eval mode with running statistics (the reference calls "
-                                    "cond_pred_model.eval() before testing, regression/card_regression.py:951)")
-                if not Ws or sc[-1] is not None:
-                    raise CardError("f_phi: BatchNorm1d must follow a Linear layer")
-                s = (m.weight if m.affine else torch.ones_like(m.running_var)) / torch.sqrt(m.running_var + m.eps)
-                sc[-1] = s
-                sh[-1] = (m.bias if m.affine else torch.zeros_like(m.running_mean)) - m.running_mean * s
-            elif isinstance(m, nn.LeakyReLU):
-                if slope is not None and slope != m.negative_slope:
-                    raise CardError("f_phi: LeakyReLU layers with different slopes")
-                slope = m.negative_slope
-            elif isinstance(m, nn.ReLU):
-                if slope not in (None, 0.0):
-                    raise CardError("f_phi: mixed activation slopes")
-                slope = 0.0
-            elif isinstance(m, nn.Dropout):
-                if m.training and m.p > 0:
-                    raise CardError("f_phi Dropout must be in eval mode (identity); call .eval() on the guidance model")
-            elif isinstance(m, nn.Identity):
-                pass
-            else:
-                raise CardError(f"f_phi: layer type {type(m).__name__} is not part of regression/model.py:70-79")
-        if not Ws:
-            raise CardError("f_phi: no Linear layer found")
-        if sc[-1] is not None:
-            raise CardError("f_phi: BatchNorm after the output layer is not part of regression/model.py:70-79")
-        device = device if device is not None else Ws[0].device
-        return cls(Ws, bs, negative_slope=0.01 if slope is None else slope, bn_scale=sc, bn_shift=sh, device=device)
+        d = describe_guidance(net)
+        device = device if device is not None else d["weights"][0].device
+        sc = [None if bn is None else _bn_fold(bn)[0] for bn in d["batchnorm"]]
+        sh = [None if bn is None else _bn_fold(bn)[1] for bn in d["batchnorm"]]
+        return cls(d["weights"], d["biases"], negative_slope=d["negative_slope"], bn_scale=sc, bn_shift=sh, device=device)
 
     @classmethod
     def from_ols(cls, beta, device=None):
@@ -118,6 +84,61 @@ class GuidanceNet:
         return out
 
     __call__ = forward
+
+
+def _bn_fold(m):
+    """eval-mode BatchNorm1d as (scale, shift) per feature"""
+    s = (m.weight if m.affine else torch.ones_like(m.running_var)) / torch.sqrt(m.running_var + m.eps)
+    return s, (m.bias if m.affine else torch.zeros_like(m.running_mean)) - m.running_mean * s
+
+
+def describe_guidance(net):
+    """Recognise f_phi (device-free, like card_amd.sampler.describe): walk the `.network` Sequential of a
+    DeterministicFeedForwardNeuralNetwork (regression/model.py:70-79) -- or any Sequential of Linear / BatchNorm1d /
+    LeakyReLU / ReLU / Dropout / Identity -- and return {"dims": [dim_in, hidden..., dim_out], "weights": [Linear.weight
+    ...], "biases": [...], "batchnorm": [the BatchNorm1d module that follows layer l, or None], "negative_slope": float}
+    with the module's own Parameter objects.  Raises CardError for train-mode BatchNorm / Dropout and foreign layers."""
+    import torch.nn as nn
+    net = getattr(net, "module", net) if isinstance(net, (nn.DataParallel, nn.parallel.DistributedDataParallel)) else net
+    seq = getattr(net, "network", net)
+    Ws, bs, bns, slope = [], [], [], None
+    for m in seq.children():
+        if isinstance(m, nn.Linear):
+            Ws.append(m.weight)
+            bs.append(m.bias)
+            bns.append(None)
+        elif isinstance(m, nn.BatchNorm1d):
+            if m.training or not m.track_running_stats:
+                raise CardError("f_phi BatchNorm1d must be in eval mode with running statistics (the reference calls "
+                                "cond_pred_model.eval() before testing, regression/card_regression.py:951)")
+            if not Ws or bns[-1] is not None:
+                raise CardError("f_phi: BatchNorm1d must follow a Linear layer")
+            bns[-1] = m
+        elif isinstance(m, nn.LeakyReLU):
+            if slope is not None and slope != m.negative_slope:
+                raise CardError("f_phi: LeakyReLU layers with different slopes")
+            slope = m.negative_slope
+        elif isinstance(m, nn.ReLU):
+            if slope not in (None, 0.0):
+                raise CardError("f_phi: mixed activation slopes")
+            slope = 0.0
+        elif isinstance(m, nn.Dropout):
+            if m.training and m.p > 0:
+                raise CardError("f_phi Dropout must be in eval mode (identity); call .eval() on the guidance model")
+        elif isinstance(m, nn.Identity):
+            pass
+        else:
+            raise CardError(f"f_phi: layer type {type(m).__name__} is not part of regression/model.py:70-79")
+    if not Ws:
+        raise CardError("f_phi: no Linear layer found")
+    if bns[-1] is not None:
+        raise CardError("f_phi: BatchNorm after the output layer is not part of regression/model.py:70-79")
+    dims = [int(Ws[0].shape[1])]
+    for l, W in enumerate(Ws):
+        if W.dim() != 2 or int(W.shape[1]) != dims[-1]:
+            raise CardError(f"f_phi layer {l}: weight {tuple(W.shape)} does not take {dims[-1]} inputs")
+        dims.append(int(W.shape[0]))
+    return {"dims": dims, "weights": Ws, "biases": bs, "batchnorm": bns, "negative_slope": 0.01 if slope is None else float(slope)}
 
 
 _gcache = weakref.WeakKeyDictionary()

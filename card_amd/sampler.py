@@ -148,6 +148,24 @@ class Sampler:
                    gamma=[sd["lin1.embed.weight"], sd["lin2.embed.weight"]], W4=sd["lin3.weight"], b4=sd["lin3.bias"],
                    device=device)
 
+    @classmethod
+    def from_description(cls, d, *, device=None):
+        """Pack what `describe(model)` found (the recognition is device-free; this is where the weights reach the GPU)."""
+        t = d.tensors
+        nl = 2 if d.variant == _lib.VARIANT_LINEAR_HADAMARD else 3
+        scale = shift = None
+        if d.variant == _lib.VARIANT_BN_HADAMARD:
+            scale, shift = [], []
+            for i in (1, 2, 3):          # eval-mode BatchNorm1d as a per-feature affine map (classification/model.py:85, :89, :92)
+                sc = t[f"bn{i}.weight"].detach().float() / torch.sqrt(t[f"bn{i}.running_var"].detach().float() + d.bn_eps)
+                scale.append(sc)
+                shift.append(t[f"bn{i}.bias"].detach().float() - t[f"bn{i}.running_mean"].detach().float() * sc)
+        device = device if device is not None else t["W1"].device
+        return cls(variant=d.variant, x_dim=d.x_dim, y_dim=d.y_dim, hidden=d.hidden, n_embed=d.n_embed, cat_x=d.cat_x,
+                   cat_y_pred=d.cat_y_pred, W=[t[f"W{i}"] for i in range(1, nl + 1)], b=[t[f"b{i}"] for i in range(1, nl + 1)],
+                   gamma=[t[f"gamma{i}"] for i in range(1, nl + 1)], W4=t["W4"], b4=t["b4"], bn_scale=scale, bn_shift=shift,
+                   device=device)
+
     def _workspace(self, N):
         """(tensor, ptr, bytes) scratch for N chains: card_sampler_workspace_bytes (0 bytes on the persistent kernel;
         bounded on the GEMM back end, which walks larger batches in chunks)."""
@@ -297,21 +315,70 @@ class Sampler:
 #     (t = T-1, where `for t in reversed(range(1, T))` starts) -- a model edited through `.data` BETWEEN two p_sample
 #     calls of one loop is the one case left to `invalidate(model)`.
 # ------------------------------------------------------------------------------------------------
-_cache = weakref.WeakKeyDictionary()
+_cache = weakref.WeakKeyDictionary()          # keyed on the CORE module (the one whose tensors are packed), not on a wrapper
 
 
-def _tensors(model):
+class ModelDescription:
+    """What `describe(model)` found: which eps_theta network of the reference `model` is, its dimensions and flags, and
+    the tensors to pack, in a fixed order.  Nothing here touches a device, so recognition and weight extraction can be
+    tested against the reference's real classes in a container without a GPU (tests/test_reference_classes_cpu.py).
+
+    kind      "guided" (regression/model.py:21), "bn_hadamard" (classification/model.py:22) or "linear_hadamard"
+              (classification/imagenet/card/builder.py:69)
+    core      the module whose parameters and buffers the sampler depends on: `model` itself with DistributedDataParallel /
+              DataParallel holders removed, or the `model_theta` of the ImageNet CARD wrapper (builder.py:8; its frozen
+              model_phi backbone is not part of the sampling path and is neither packed nor hashed)
+    tensors   ordered name -> tensor (the module's own Parameter / buffer objects): W1 b1 gamma1 ... W4 b4
+              [+ bn{i}.weight / .bias / .running_mean / .running_var]; for the ImageNet head W4 / b4 are its lin3
+    features  how the kernels' `x` is obtained from the caller's x: None (x itself), "norm(encoder_x(x))" or "linx(z)"
+    """
+    __slots__ = ("kind", "variant", "core", "x_dim", "y_dim", "hidden", "n_embed", "cat_x", "cat_y_pred", "bn_eps",
+                 "tensors", "features", "wrapped")
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw[k])
+
+    @property
+    def d_in(self):
+        """columns of lin1: y_t, then y_0_hat when cat_y_pred, then x when cat_x (regression/model.py:37-47)"""
+        return int(self.tensors["W1"].shape[1])
+
+    def __repr__(self):
+        return (f"ModelDescription({self.kind}, x_dim={self.x_dim}, y_dim={self.y_dim}, hidden={self.hidden}, "
+                f"n_embed={self.n_embed}, cat_x={self.cat_x}, cat_y_pred={self.cat_y_pred}, features={self.features!r}, "
+                f"wrapped={self.wrapped})")
+
+
+def unwrap(model):
+    """`model` without its DistributedDataParallel / DataParallel holders: classification/imagenet/main.py:222-237 wraps the
+    CARD model before handing it to p_sample_loop (:482, :557) and itself reaches in with `model.module` (:357).  Any
+    other holder that only carries a `.module` nn.Module (apex DDP, a bare container) is unwrapped the same way when the
+    holder itself has none of the eps_theta attributes."""
+    import torch.nn as nn
+    for _ in range(4):
+        inner = getattr(model, "module", None)
+        if not isinstance(inner, nn.Module):
+            break
+        if isinstance(model, (nn.parallel.DistributedDataParallel, nn.DataParallel)) or not hasattr(model, "lin1"):
+            model = inner
+        else:
+            break
+    return model
+
+
+def _tensors(core):
     import itertools
-    return list(itertools.chain(model.parameters(), model.buffers()))
+    return list(itertools.chain(core.parameters(), core.buffers()))
 
 
-def _fingerprint(model):
-    return tuple((id(p), p.data_ptr(), p._version) for p in _tensors(model))
+def _fingerprint(core):
+    return tuple((id(p), p.data_ptr(), p._version) for p in _tensors(core))
 
 
-def _content_hash(model):
+def _content_hash(core):
     """card_content_hash of every parameter and buffer (device-side, one launch; reads back 8 bytes)."""
-    ts = [p.detach() for p in _tensors(model) if p.numel() > 0]
+    ts = [p.detach() for p in _tensors(core) if p.numel() > 0]
     ts = [t if t.is_contiguous() else t.contiguous() for t in ts]
     if not ts or ts[0].device.type != "cuda":
         return 0
@@ -330,94 +397,181 @@ def _content_hash(model):
     return total
 
 
-def invalidate(model):
-    """Forget the packed sampler (and hoisted features) of `model`: the next call re-packs from the current weights."""
-    _cache.pop(model, None)
-    _xfeat_cache.pop(model, None)
+def _is_cond_linear(m):
+    # ConditionalLinear (regression/model.py:6, classification/model.py:7, imagenet/card/builder.py:54): .lin + .embed
+    return hasattr(m, "lin") and hasattr(m, "embed") and hasattr(m.lin, "weight") and hasattr(m.embed, "weight")
 
 
 def _is_guided(model):
     # regression/model.py:21 ConditionalGuidedModel, recognised by structure (duck-typed `model` contract)
     return all(hasattr(model, n) for n in ("lin1", "lin2", "lin3", "lin4", "cat_x", "cat_y_pred")) and \
-        hasattr(model.lin1, "lin") and hasattr(model.lin1, "embed") and not hasattr(model, "unetnorm1")
+        _is_cond_linear(model.lin1) and not hasattr(model, "unetnorm1")
 
 
 def _is_cls(model):
     # classification/model.py:22 ConditionalModel: lin1..lin4 + unetnorm1..3 + encoder_x + norm
     return all(hasattr(model, n) for n in ("lin1", "lin2", "lin3", "lin4", "unetnorm1", "unetnorm2", "unetnorm3",
-                                           "encoder_x", "norm"))
-
-
-_xfeat_cache = weakref.WeakKeyDictionary()
+                                           "encoder_x", "norm")) and _is_cond_linear(model.lin1)
 
 
 def _imagenet_theta(model):
     # classification/imagenet/card/builder.py: the CARD wrapper (:8, model_theta attribute) or the bare head (:69)
     theta = getattr(model, "model_theta", model)
-    ok = all(hasattr(theta, n) for n in ("linx", "lin1", "lin2", "lin3")) and not hasattr(theta, "lin4")
+    ok = all(hasattr(theta, n) for n in ("linx", "lin1", "lin2", "lin3")) and not hasattr(theta, "lin4") and \
+        _is_cond_linear(theta.lin1) and _is_cond_linear(theta.lin2) and not _is_cond_linear(theta.lin3)
     return theta if ok else None
+
+
+def _shape_check(what, t, want):
+    if tuple(t.shape) != tuple(want):
+        raise CardError(f"{what}: shape {tuple(t.shape)}, expected {tuple(want)}")
+
+
+def describe(model):
+    """Recognise `model` (device-free) and list what the sampler packs from it: a ModelDescription.  Raises CardError
+    for anything that is not one of the reference's three eps_theta networks (there is no eager fallback)."""
+    inner = unwrap(model)
+    wrapped = inner is not model
+    t = {}
+
+    def cond(i, m):
+        t[f"W{i}"], t[f"b{i}"], t[f"gamma{i}"] = m.lin.weight, m.lin.bias, m.embed.weight
+
+    if _is_guided(inner):
+        core, kind, variant, features, bn_eps = inner, "guided", _lib.VARIANT_GUIDED, None, None
+        for i in (1, 2, 3):
+            cond(i, getattr(core, f"lin{i}"))
+        t["W4"], t["b4"] = core.lin4.weight, core.lin4.bias
+        cat_x, cat_y_pred = bool(core.cat_x), bool(core.cat_y_pred)
+        y_dim, hidden, d_in = int(t["W4"].shape[0]), int(t["W1"].shape[0]), int(t["W1"].shape[1])
+        x_dim = d_in - y_dim - (y_dim if cat_y_pred else 0) if cat_x else 0
+        if x_dim < 0 or (not cat_x and d_in != y_dim * (2 if cat_y_pred else 1)):
+            raise CardError(f"lin1 takes {d_in} inputs, which does not fit y_dim={y_dim}, cat_x={cat_x}, cat_y_pred={cat_y_pred} "
+                            "(regression/model.py:27-32)")
+    elif _imagenet_theta(inner) is not None:
+        core, kind, variant, features, bn_eps = _imagenet_theta(inner), "linear_hadamard", _lib.VARIANT_LINEAR_HADAMARD, "linx(z)", None
+        wrapped = wrapped or core is not inner
+        cond(1, core.lin1)
+        cond(2, core.lin2)
+        t["W4"], t["b4"] = core.lin3.weight, core.lin3.bias
+        cat_x, cat_y_pred = False, bool(getattr(core, "guidance", True))
+        y_dim, hidden = int(t["W4"].shape[0]), int(t["W1"].shape[0])
+        x_dim = hidden
+        _shape_check("linx.weight", core.linx.weight, (hidden, core.linx.weight.shape[1]))
+    elif _is_cls(inner):
+        core, kind, variant, features = inner, "bn_hadamard", _lib.VARIANT_BN_HADAMARD, "norm(encoder_x(x))"
+        for i in (1, 2, 3):
+            cond(i, getattr(core, f"lin{i}"))
+            bn = getattr(core, f"unetnorm{i}")
+            if getattr(bn, "running_mean", None) is None or getattr(bn, "weight", None) is None:
+                raise CardError(f"unetnorm{i} has no running statistics / affine parameters to fold (classification/model.py:72-76 "
+                                "builds nn.BatchNorm1d with both)")
+            t[f"bn{i}.weight"], t[f"bn{i}.bias"] = bn.weight, bn.bias
+            t[f"bn{i}.running_mean"], t[f"bn{i}.running_var"] = bn.running_mean, bn.running_var
+        t["W4"], t["b4"] = core.lin4.weight, core.lin4.bias
+        eps = {float(getattr(core, f"unetnorm{i}").eps) for i in (1, 2, 3)}
+        if len(eps) != 1:
+            raise CardError(f"unetnorm1..3 use different eps values {sorted(eps)}")
+        bn_eps = eps.pop()
+        cat_x, cat_y_pred = False, bool(getattr(core, "guidance", True))
+        y_dim, hidden = int(t["W4"].shape[0]), int(t["W1"].shape[0])
+        x_dim = hidden
+    else:
+        raise CardError(f"card_amd does not recognise {type(inner).__name__} as a CARD eps_theta network "
+                        "(expected regression ConditionalGuidedModel, classification ConditionalModel or the ImageNet head, "
+                        "bare or inside DistributedDataParallel / DataParallel); there is no eager fallback")
+    n_embed = int(t["gamma1"].shape[0])
+    nl = 2 if variant == _lib.VARIANT_LINEAR_HADAMARD else 3
+    if variant != _lib.VARIANT_GUIDED:
+        _shape_check("lin1.lin.weight", t["W1"], (hidden, y_dim * (2 if cat_y_pred else 1)))
+    for i in range(1, nl + 1):
+        if i > 1:
+            _shape_check(f"lin{i}.lin.weight", t[f"W{i}"], (hidden, hidden))
+        _shape_check(f"lin{i}.lin.bias", t[f"b{i}"], (hidden,))
+        _shape_check(f"lin{i}.embed.weight", t[f"gamma{i}"], (n_embed, hidden))
+        if variant == _lib.VARIANT_BN_HADAMARD:
+            for k in ("weight", "bias", "running_mean", "running_var"):
+                _shape_check(f"unetnorm{i}.{k}", t[f"bn{i}.{k}"], (hidden,))
+    _shape_check("output layer weight", t["W4"], (y_dim, hidden))
+    _shape_check("output layer bias", t["b4"], (y_dim,))
+    order = [f"{p}{i}" for i in range(1, nl + 1) for p in ("W", "b", "gamma")] + ["W4", "b4"] + \
+        [f"bn{i}.{k}" for i in (1, 2, 3) for k in ("weight", "bias", "running_mean", "running_var") if f"bn{i}.{k}" in t]
+    return ModelDescription(kind=kind, variant=variant, core=core, x_dim=x_dim, y_dim=y_dim, hidden=hidden, n_embed=n_embed,
+                            cat_x=cat_x, cat_y_pred=cat_y_pred, bn_eps=bn_eps, tensors={k: t[k] for k in order},
+                            features=features, wrapped=wrapped)
+
+
+def core_of(model):
+    """The module the caches are keyed on (see ModelDescription.core); cheap enough for every call."""
+    inner = unwrap(model)
+    theta = getattr(inner, "model_theta", None)
+    if theta is not None and hasattr(theta, "linx"):
+        return theta
+    return inner
+
+
+def invalidate(model):
+    """Forget the packed sampler (and hoisted features) of `model`: the next call re-packs from the current weights."""
+    core = core_of(model)
+    _cache.pop(core, None)
+    _xfeat_cache.pop(core, None)
+
+
+_xfeat_cache = weakref.WeakKeyDictionary()
 
 
 def x_features(model, x):
     """x_feat = norm(encoder_x(x)) (classification/model.py:80-81) or linx(z) (imagenet/card/builder.py:90), computed
     ONCE per x tensor object instead of once per timestep: in eval mode it does not depend on t or y.  The cache entry
     is tied to the x OBJECT through a weak reference (an address alone can be recycled by the caching allocator for the
-    next batch) and dies with it, so the features are not pinned beyond the caller's own x.
+    next batch) and dies with it, so the features are not pinned beyond the caller's own x.  `model` may be wrapped
+    (DistributedDataParallel / DataParallel / the ImageNet CARD wrapper): the inner module is used, like the reference's
+    own `model.module.model_theta` (imagenet/main.py:357).
     Stock PyTorch-ROCm (out of scope to fuse)."""
-    hit = _xfeat_cache.get(model)
-    if hit is not None and hit[0]() is x and hit[1] == (x._version, _cache.get(model, (None,))[0]):
+    core = core_of(model)
+    hit = _xfeat_cache.get(core)
+    if hit is not None and hit[0]() is x and hit[1] == (x._version, _cache.get(core, (None,))[0]):
         return hit[2]
-    theta = _imagenet_theta(model)
     with torch.no_grad():
-        xf = (theta.linx(x) if theta is not None else model.norm(model.encoder_x(x))).float().contiguous()
+        xf = (core.linx(x) if hasattr(core, "linx") else core.norm(core.encoder_x(x))).float().contiguous()
     if xf is x:                  # identity encoder: nothing was computed, and caching x under its own weak key would pin it
         return xf
-    mref = weakref.ref(model)
+    mref = weakref.ref(core)
 
     def _drop(_, mref=mref):
         m = mref()
         if m is not None:
             _xfeat_cache.pop(m, None)
 
-    _xfeat_cache[model] = (weakref.ref(x, _drop), (x._version, _cache.get(model, (None,))[0]), xf)
+    _xfeat_cache[core] = (weakref.ref(x, _drop), (x._version, _cache.get(core, (None,))[0]), xf)
     return xf
 
 
 def sampler_for(model, check_content=True):
     """The cached Sampler of an eps_theta `nn.Module` (raises for architectures the kernels do not cover).
     check_content=False skips the content hash (per-timestep callers inside one loop)."""
-    if getattr(model, "training", False) and hasattr(model, "unetnorm1"):
+    core = core_of(model)
+    if getattr(core, "training", False) and hasattr(core, "unetnorm1"):
         raise CardError("card_amd samples a BatchNorm model in eval mode only: in train mode BatchNorm normalises with "
                         "batch statistics and the folded (scale, shift) would be wrong (call model.eval(); the "
                         "reference tests under model.eval(), classification/card_classification.py:873)")
-    fp = _fingerprint(model)
-    hit = _cache.get(model)
+    fp = _fingerprint(core)
+    hit = _cache.get(core)
     if hit is not None and hit[0] == fp:
         if not check_content:
             return hit[1]
-        h = _content_hash(model)
+        h = _content_hash(core)
         if h == hit[2]:
             return hit[1]
     else:
         h = None
-    device = next(model.parameters()).device
+    d = describe(model)
+    assert d.core is core
+    # no train/eval-dependent layer in regression/model.py:21-51: the reference samples from it in train mode too
+    # (validation inside train(), regression/card_regression.py:365 -> :457, :533)
+    device = d.tensors["W1"].device
     _require_cuda(device)
-    if _is_guided(model):
-        # no train/eval-dependent layer in regression/model.py:21-51: the reference samples from it in train mode too
-        # (validation inside train(), regression/card_regression.py:365 -> :457, :533)
-        s = Sampler.from_state_dict(model.state_dict(), cat_x=bool(model.cat_x), cat_y_pred=bool(model.cat_y_pred),
-                                    device=device)
-    elif _imagenet_theta(model) is not None:
-        theta = _imagenet_theta(model)
-        s = Sampler.from_imagenet_head_state_dict(theta.state_dict(), guidance=bool(getattr(theta, "guidance", True)),
-                                                  device=device)
-    elif _is_cls(model):
-        s = Sampler.from_cls_state_dict(model.state_dict(), guidance=bool(getattr(model, "guidance", True)),
-                                        bn_eps=float(model.unetnorm1.eps), device=device)
-    else:
-        raise CardError(f"card_amd does not recognise {type(model).__name__} as a CARD eps_theta network "
-                        "(expected regression ConditionalGuidedModel, classification ConditionalModel or the ImageNet head); "
-                        "there is no eager fallback")
-    _cache[model] = (fp, s, _content_hash(model) if h is None else h)
-    _xfeat_cache.pop(model, None)
+    s = Sampler.from_description(d, device=device)
+    _cache[core] = (fp, s, _content_hash(core) if h is None else h)
+    _xfeat_cache.pop(core, None)
     return s
