@@ -85,6 +85,13 @@ def main():
                     help="f32 = FP32 MFMA (default, the headline line); split = CARD_ARITH_SPLIT_BF16: the hidden layers as six "
                          "bf16 MFMAs per k-step on exact three-way bf16 cuts of the fp32 operands (hidden-128 regression only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend under torch.distributed.run: nccl (= RCCL, the default and what the driver "
+                         "uses) or gloo (a rehearsal of the multi-rank path on a box with fewer GPUs than ranks: barrier, the "
+                         "evaluation sums and the max-over-ranks time go through the host)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="every rank uses cuda:0 instead of cuda:LOCAL_RANK (with --backend gloo: N ranks rehearsed on one GPU; "
+                         "the ranks then share the GPU's time, so `value` says nothing about scaling)")
     a = ap.parse_args()
 
     # stdout carries exactly one JSON line: route everything libraries print there (the RCCL banner ...) to stderr
@@ -98,12 +105,19 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if a.share_device:
+        if a.backend != "gloo" and world > 1:
+            sys.exit("--share-device puts every rank on cuda:0; RCCL needs one GPU per rank (use --backend gloo)")
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = "RANK" in os.environ          # launched by torch.distributed.run (also with one rank)
     if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from card_amd import _lib
     from card_amd.sampler import Sampler, make_coef_table
@@ -186,7 +200,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=dev if a.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert torch.isfinite(y).all()
@@ -272,7 +286,8 @@ def main():
             "config": {"workload": f"{desc}: {a.rows} test rows x {a.nz} z-samples per GPU, x_dim={x_dim} "
                                    f"(d_in={d_in}), H={H}, y_dim={y_dim}, T={T}, in-kernel Philox noise, last-sample "
                                    "output, random-init weights",
-                       "rows_per_gpu": a.rows, "n_z": a.nz, "T": T, "sharding": f"rows x{world}, no data-path collective"},
+                       "rows_per_gpu": a.rows, "n_z": a.nz, "T": T, "sharding": f"rows x{world}, no data-path collective",
+                       "backend": (a.backend if use_dist else None), "ranks_share_one_gpu": bool(a.share_device and world > 1)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
                          "kernel": kernel, "flops_per_sample_step": flops_per_unit,

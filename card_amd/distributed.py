@@ -99,6 +99,16 @@ def sharded_regression_metrics(y0_local: torch.Tensor, y_true_local: torch.Tenso
 
 
 def all_reduce_sums(sums: torch.Tensor, group=None) -> torch.Tensor:
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    """Sum `sums` over the ranks of `group`, in place.  Whenever a process group is initialised the collective is ISSUED,
+    also with one rank (so the one-rank nccl test and a one-rank `torch.distributed.run bench.py` line do send the
+    float64 (1, 16) device vector through RCCL's all-reduce); without a process group it is the identity.  Under the
+    gloo backend (CPU rehearsals; `bench.py --backend gloo --share-device`) a device vector is summed through the host."""
+    if not dist.is_initialized():
+        return sums
+    if sums.is_cuda and dist.get_backend(group) == "gloo":
+        host = sums.cpu()
+        dist.all_reduce(host, group=group)
+        sums.copy_(host)
+    else:
         dist.all_reduce(sums, group=group)
     return sums

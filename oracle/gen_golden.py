@@ -331,6 +331,75 @@ def gen_classification_synth(cls_du, cls_model, name, dataset, data_dim, C, Fdim
     print(f"{name}: N={N} T={T} C={C} F={Fdim} max|y|={traj.abs().max():.3f}")
 
 
+def gen_classification_synth_trained(cls_du, cls_model, name, dataset, data_dim, C, Fdim, T, N, seed, train_steps, keep_every=50):
+    """The CIFAR-10 head at its REAL horizon (classification/configs/cifar10.yml: F = 4096, T = 1000, beta 1e-4 .. 0.02) with
+    trajectories that stay O(1) like a trained CARD's.  With random weights 1000 reverse steps drive |y| to ~500 (measured),
+    and a fully trained F = 4096 model cannot travel (2 x 64 MB of weights + 48 MB of gamma tables).  So the reference model
+    carries card_amd.synth's seeded weights, the big tensors (lin2 / lin3 weight matrices, the three gamma tables) and the
+    encoder stay FROZEN at those values, and only the small tensors -- lin1, lin4, every bias, the unetnorm affine
+    parameters (and, through train mode, their running statistics): 160 k numbers -- are trained with the reference's own
+    noise-estimation loss (classification/card_classification.py: e ~ N(0,1), y_t = q_sample(y, y_0_hat, ..., t, noise=e),
+    loss = (e - model(x, y_t, t, y_0_hat))^2.mean()).  The fixture holds the seed, those small tensors (sd.*: overrides
+    of the seeded dict), the inputs and the reference's outputs; the GPU test regenerates the big tensors from the seed."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from card_amd.synth import cls_state_dict
+    torch.manual_seed(seed)
+    cfg = NS(diffusion=NS(timesteps=T),
+             model=NS(data_dim=data_dim, arch="linear", feature_dim=Fdim, hidden_dim=Fdim),
+             data=NS(num_classes=C, dataset=dataset))
+    model = cls_model.ConditionalModel(cfg, guidance=True)
+    missing, unexpected = model.load_state_dict(cls_state_dict(Fdim, C, T, seed), strict=False)
+    assert not unexpected and all(k.startswith(("encoder_x", "norm.")) for k in missing), (missing, unexpected)
+    frozen = {"lin2.lin.weight", "lin3.lin.weight", "lin1.embed.weight", "lin2.embed.weight", "lin3.embed.weight"}
+    for n_, p_ in model.named_parameters():
+        if n_ in frozen or n_.startswith(("encoder_x", "norm.")):
+            p_.requires_grad_(False)
+    small = [n_ for n_, p_ in model.named_parameters() if p_.requires_grad]
+    alphas, abs_, omabs = schedule(cls_du, "linear", T, 1e-4, 0.02)          # cifar10.yml: beta_start / beta_end
+    g = torch.Generator().manual_seed(seed)
+    Wc = torch.randn(data_dim, C, generator=g) / data_dim ** 0.5
+    opt = torch.optim.Adam([p_ for p_ in model.parameters() if p_.requires_grad], lr=2e-3)
+    model.train()
+    model.encoder_x.eval()          # the frozen encoder keeps its (default) BatchNorm statistics
+    model.norm.eval()
+    for it in range(train_steps):
+        x = torch.randn(128, data_dim)
+        logits = x @ Wc * 3.0
+        y = torch.nn.functional.one_hot(logits.argmax(1), C).float()
+        y0hat = torch.softmax(logits + 0.5 * torch.randn(128, C), 1)
+        t = torch.randint(0, T, (128,))
+        e = torch.randn_like(y)
+        y_t = cls_du.q_sample(y, y0hat, abs_, omabs, t, noise=e)
+        loss = (e - model(x, y_t, t, y0hat)).square().mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    print(f"  trained {len(small)} small tensors for {train_steps} steps, loss {float(loss.detach()):.4f}")
+    model.eval()
+    x = torch.randn(N, data_dim)
+    y0hat = torch.softmax(x @ Wc * 3.0 + 0.5 * torch.randn(N, C), 1)
+    with torch.no_grad():
+        x_feat = model.norm(model.encoder_x(x))
+    noise, seq = run_loop(cls_du, model, x, y0hat, y0hat, T, alphas, omabs, seed + 1)
+    traj = torch.stack(seq, 0)
+    assert torch.equal(seq[0], noise[0] + y0hat)
+    keep = sorted(set(list(range(0, T + 1, keep_every)) + [T - 1, T]))
+    probes = {}
+    with torch.no_grad():
+        for t in (T - 1, T // 2, 1):
+            probes[f"eps.t{t}"] = model(x, traj[T - t], torch.tensor([t]), y0hat).numpy()
+        probes["last"] = cls_du.p_sample_t_1to0(model, x, traj[T - 1], y0hat, y0hat, omabs).numpy()
+    sdm = model.state_dict()
+    over = {"sd." + k: sdm[k].detach().numpy() for k in sdm
+            if (k in small or "running_" in k) and k.startswith(("lin", "unetnorm"))}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), kind="classification_synth", T=T, seed=seed, F=Fdim, C=C,
+                        x_feat=x_feat.numpy(), y0hat=y0hat.numpy(), yTmean=y0hat.numpy(), alphas=alphas.numpy(),
+                        alphas_bar_sqrt=abs_.numpy(), omabs=omabs.numpy(), noise=noise.numpy(), traj_idx=np.asarray(keep),
+                        traj=traj[keep].numpy(), probe_t=np.asarray([T - 1, T // 2, 1]), **probes, **over)
+    print(f"{name}: N={N} T={T} C={C} F={Fdim} max|y|={traj.abs().max():.3f} |y_0|max={traj[-1].abs().max():.3f} "
+          f"overrides={sorted(over)}")
+
+
 def reference_metric_closures(tau):
     """The metric helpers are closures inside Diffusion.test (regression/card_regression.py:763-825, :866-893): pull
     their FunctionDef nodes out of the reference source with `ast`, re-home them in a factory `make(self)` (they read
@@ -543,6 +612,9 @@ def main():
     S = lambda name, *a: job(name, gen_classification_synth, cls_du, cls_model, name, *a)
     S("clsw_cifar10_T50", "CIFAR10", 3072, 10, 4096, 50, 24, 23)       # classification/configs/cifar10.yml:15-19
     S("clsw_c100_T50", "CIFAR100", 64, 100, 256, 50, 24, 24)
+    # BASELINE configs[3] at its real horizon: F = 4096, C = 10, T = 1000, beta 1e-4 .. 0.02 (cifar10.yml); every 50th state
+    job("clsw_cifar10_T1000", gen_classification_synth_trained, cls_du, cls_model, "clsw_cifar10_T1000", "CIFAR10", 3072, 10,
+        4096, 1000, 8, 26, 600)
     inet_job("inet_head_T10", 20, 128, 10, 24, 31)
     M = lambda name, *a, **k: job(name, gen_metrics, name, *a, **k)
     M("metrics_nz1000_global_tau", 97, 1000, 1, scaler=True, tau=0.37, trim=(0, 100))

@@ -31,7 +31,9 @@ def load_golden(name):
         # wide heads: the fixture holds the seed, inputs and the reference's outputs; the theta weights are
         # card_amd.synth.cls_state_dict(F, C, T, seed), which the reference model carried when the fixture was made
         from card_amd.synth import cls_state_dict
+        over = sd
         sd = cls_state_dict(int(d["F"]), int(d["C"]), int(d["T"]), int(d["seed"]))
+        sd.update(over)                   # trained small tensors stored next to the seed (clsw_cifar10_T1000)
     t = lambda k: torch.from_numpy(d[k])
     out = dict(raw=d, sd=sd, T=int(d["T"]), kind=str(d["kind"]),
                x=t("x") if "x" in d else (t("z") if "z" in d else t("x_feat")), y0hat=t("y0hat"), yTmean=t("yTmean"), alphas=t("alphas"), omabs=t("omabs"),
@@ -72,6 +74,27 @@ def elem_errs(got, ref):
     d = (got - ref).abs()
     floor = max(1e-30, 1e-3 * float(ref.abs().max()))
     return norm_rel_err(got, ref), float(d.max()), float((d / ref.abs().clamp_min(floor)).max())
+
+
+PARITY_LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_table.jsonl")
+
+
+def record_parity(fixture, kernel, errs, mode="free-running"):
+    """Append one measured parity line {fixture, kernel / form, mode, norm_rel, max_abs, max_elem_rel} to
+    gpurun_out/parity_table.jsonl (scratch; merged back from the GPU box).  tools/collect_parity.py folds the file into
+    profiles/r03_parity_table.json -- `pytest -q` drops what the tests print, this keeps it."""
+    import json
+    try:
+        os.makedirs(os.path.dirname(PARITY_LOG), exist_ok=True)
+        with open(PARITY_LOG, "a") as f:
+            f.write(json.dumps({"fixture": fixture, "kernel": kernel, "mode": mode, "norm_rel": errs[0], "max_abs": errs[1],
+                                "max_elem_rel": errs[2]}) + "\n")
+    except OSError:
+        pass                      # a read-only checkout: the table is evidence, not part of the assertion
+
+
+def worst_errs(errs):
+    return tuple(max(e[j] for e in errs) for j in range(3))
 
 
 def fmt_errs(e):

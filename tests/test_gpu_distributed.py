@@ -61,7 +61,16 @@ def one_rank_nccl():
 
 def test_rccl_branches_under_a_one_rank_group(one_rank_nccl):
     """gather=True goes through dist.all_gather (padded shards, trimmed), the metric sums through dist.all_reduce, both on
-    RCCL with device tensors; with one rank they must return what the local computation gives."""
+    RCCL with device tensors (all_reduce_sums issues the collective whenever a group exists, also with one rank -- counted
+    below); with one rank they must return what the local computation gives."""
+    calls = []
+    real = dist.all_reduce
+
+    def counting(t, *a, **k):
+        calls.append((t.device.type, t.dtype, tuple(t.shape)))
+        return real(t, *a, **k)
+
+    dist.all_reduce = counting
     g, m, x, y0, n_z = _problem(rows=11, n_z=64)
     al, om = cuda(g["alphas"]), cuda(g["omabs"])
     local, (lo, hi) = cd.sharded_sample_y0(m, x, y0, y0, n_z, g["T"], al, om, seed=5, gather=False)
@@ -69,9 +78,52 @@ def test_rccl_branches_under_a_one_rank_group(one_rank_nccl):
     full = cd.sharded_sample_y0(m, x, y0, y0, n_z, g["T"], al, om, seed=5, gather=True)
     assert torch.equal(full, local)
     y_true = y0 + 0.2
-    fin, sums = cd.sharded_regression_metrics(local, y_true, tau=1.0)
+    try:
+        fin, sums = cd.sharded_regression_metrics(local, y_true, tau=1.0)
+    finally:
+        dist.all_reduce = real
+    assert calls == [("cuda", torch.float64, (1, 16))], calls          # the 16-number vector did go through ncclAllReduce
     want = metrics.regression_metric_sums(local, y_true, tau=1.0)
     assert torch.equal(sums, want) and sums.shape == (1, 16) and float(sums[0, 0]) == 11
     one = metrics.finalize(want)
     for k in ("rmse", "picp", "nll", "qice"):
         assert float(fin[k][0]) == float(one[k][0])
+
+
+def _bench_child(extra, nproc=None, timeout=420):
+    """bench.py as a fresh child process (optionally under torch.distributed.run); returns its one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable]
+    if nproc:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+                "--master-port", str(29700 + os.getpid() % 200)]
+    cmd += [os.path.join(root, "bench.py")] + extra
+    r = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (r.stdout, r.stderr[-2000:])          # rank 0 only, exactly one JSON line
+    return json.loads(lines[0])
+
+
+def test_two_rank_bench_line_on_one_gpu_through_gloo():
+    """The N > 1 path of bench.py executed for real on the one GPU a test box has: two ranks under torch.distributed.run,
+    both on cuda:0 (--share-device), process group on gloo (--backend gloo: RCCL needs one GPU per rank).  Exercises what
+    a driver-launched N = 2 run does outside the kernels -- RANK / WORLD_SIZE from the environment, per-rank seeds and
+    `elem_offset = rank * N * y_dim`, dist.barrier on both sides of the timed region, the evaluation sums from the HIP
+    metrics kernel through all_reduce, the max-over-ranks time, rank-0-only JSON.  The two ranks share the GPU's time, so
+    the whole-job value must come out near the one-rank value (not near twice it): 1 049 rows x 1000 z = one full
+    launch of the persistent kernel per rank and step."""
+    common = ["--workload", "toy", "--rows", "1049", "--nz", "1000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    one = _bench_child(["--gpus", "1"] + common)
+    two = _bench_child(["--gpus", "2", "--backend", "gloo", "--share-device"] + common, nproc=2)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["steps"] == 2 and two["scaling"] == "weak"
+    assert two["config"]["backend"] == "gloo" and two["config"]["ranks_share_one_gpu"] is True
+    ratio = two["value"] / one["value"]
+    print(f"1 rank {one['value']:.3e}, 2 ranks sharing the GPU {two['value']:.3e} sample-steps/s (ratio {ratio:.3f})")
+    assert 0.80 <= ratio <= 1.15, ratio

@@ -13,7 +13,7 @@ import card_amd
 from card_amd import _lib
 from card_amd.sampler import Sampler, make_coef_table
 from oracle import card_oracle as orc
-from tests.helpers import golden_names, load_golden, norm_rel_err, elem_errs, fmt_errs
+from tests.helpers import golden_names, load_golden, norm_rel_err, elem_errs, fmt_errs, record_parity, worst_errs
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -64,7 +64,7 @@ def small_batch_kernel(request, monkeypatch):
 
 
 @pytest.mark.parametrize("name", SUPPORTED_REG)
-def test_free_running_loop_matches_reference(name):
+def test_free_running_loop_matches_reference(name, small_batch_kernel):
     g = load_golden(name)
     m = model_of(g)
     T = g["T"]
@@ -75,7 +75,8 @@ def test_free_running_loop_matches_reference(name):
     assert torch.equal(traj[0], g["noise"][0] + g["yTmean"])
     errs = [elem_errs(traj[k], g["traj"][i]) for i, k in enumerate(g["traj_idx"])]
     worst = max(e[0] for e in errs)
-    print(f"{name}: worst per-state {fmt_errs(tuple(max(e[j] for e in errs) for j in range(3)))}")
+    print(f"{name}: worst per-state {fmt_errs(worst_errs(errs))}")
+    record_parity(name, "card_sample_coop16_kernel" if small_batch_kernel == "coop" else "card_sample_guided_kernel", worst_errs(errs))
     assert worst <= TOL
     # only_last_sample (classification/diffusion_utils.py:136-139) and a state selection
     y0 = card_amd.p_sample_loop(m, cuda(g["x"]), cuda(g["y0hat"]), cuda(g["yTmean"]), T, cuda(g["alphas"]),
@@ -111,18 +112,21 @@ def test_teacher_forced_steps_and_eps(name):
 
 
 @pytest.mark.parametrize("name", ["reg_boston_T50", "reg_toy_T50"])
-def test_every_step_teacher_forced_against_oracle(name):
+def test_every_step_teacher_forced_against_oracle(name, small_batch_kernel):
     """Feed the reference y_t at EVERY timestep, compare y_{t-1} (SURVEY.md section 8c teacher-forced metric)."""
     g = load_golden(name)
     m, T = model_of(g), g["T"]
     assert g["traj_idx"] == list(range(T + 1))
-    worst = 0.0
+    errs = []
     for t in range(T - 1, 0, -1):
         # timestep t maps list position T-1-t to position T-t and consumes noise draw T-t
         out = card_amd.p_sample(m, cuda(g["x"]), cuda(g["traj"][T - 1 - t]), cuda(g["y0hat"]), cuda(g["yTmean"]), t,
                                 cuda(g["alphas"]), cuda(g["omabs"]), noise=cuda(g["noise"][T - t])).cpu()
-        worst = max(worst, norm_rel_err(out, g["traj"][T - t]))
-    print(f"{name}: worst teacher-forced err {worst:.3e}")
+        errs.append(elem_errs(out, g["traj"][T - t]))
+    worst = max(e[0] for e in errs)
+    print(f"{name}: worst teacher-forced {fmt_errs(worst_errs(errs))}")
+    record_parity(name, "card_sample_coop16_kernel" if small_batch_kernel == "coop" else "card_sample_guided_kernel", worst_errs(errs),
+                  mode="teacher-forced, every timestep")
     assert worst <= TOL
 
 

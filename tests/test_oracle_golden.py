@@ -16,12 +16,14 @@ TOL = 2e-6
 @pytest.mark.parametrize("name", golden_names())
 def test_loop_matches_reference(name):
     g = load_golden(name)
-    torch.set_num_threads(4)
+    torch.set_num_threads(8 if g["T"] * g["x_in"].shape[1] > 1_000_000 else 4)
     seq = orc.p_sample_loop(g["weights"], g["x_in"], g["y0hat"], g["yTmean"], g["T"], g["alphas"], g["omabs"],
                             g["noise"])
     assert len(seq) == g["T"] + 1
     traj = torch.stack(seq, 0)[g["traj_idx"]]
     assert norm_rel_err(traj, g["traj"]) <= TOL
+    if g["T"] * g["x_in"].shape[1] > 1_000_000:
+        return                    # clsw_cifar10_T1000: one pass of the oracle is ~30 s of CPU; the flag is covered by every other fixture
     y0 = orc.p_sample_loop(g["weights"], g["x_in"], g["y0hat"], g["yTmean"], g["T"], g["alphas"], g["omabs"],
                            g["noise"], only_last_sample=True)
     assert torch.equal(y0, seq[-1])
