@@ -139,6 +139,8 @@ def test_cls_wide_widths_match_reference(name, f128_kernel):
         assert torch.equal(got, s.run(xf, y0, cuda(g["yTmean"]), coef, T, noise=cuda(g["noise"]), out_mode=_lib.OUT_ALL).cpu())
     full = dict(zip(idx, g["traj"]))
     for t in g["probe_t"]:
+        if T - t not in full:      # a fixture that keeps every 50th state holds no y_t for the probe at t = T - 1
+            continue
         eps = s.eps_theta(xf, cuda(full[T - t]), y0, t).cpu()
         assert norm_rel_err(eps, d[f"eps.t{t}"]) <= TOL, t
     if "last" in d:          # p_sample_t_1to0 from the reference's y_1 (teacher-forced last step)
