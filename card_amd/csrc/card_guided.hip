@@ -435,14 +435,20 @@ constexpr int kCoopWaves = 4;
 constexpr int kCoopThreads = kCoopWaves * 64;
 constexpr int kExLd = kH + 4;                          // exchange tile row stride (floats): conflict-free b128
 constexpr int kTabFloats = kOffW1 + kH - kOffB;        // b1|b2|b3|W4|b4|W1[:,0] as they sit in the packed image
-constexpr int kCoopLdsFloats = 2 * kTileM * kExLd + kCoopWaves * kTileM + 2 * kGammaRow + kTabFloats;
+// Philox draws of a tile, shared: every lane of the four waves used to run the generator for its own chain -- the same
+// call on all 8 (wave, lane half) copies of a chain, ~1 500 cycles per wave every 4 timesteps.  Now copy (w, hh) draws
+// block 8 grp + 2w + hh of chain m, i.e. one call per lane covers 32 timesteps of the tile, and the normals wait in LDS
+// as [block & 7][draw & 3][chain] (conflict-free b32 reads).  Same generator, same (seed, element, block) -> same bits.
+constexpr int kZFloats = 8 * 4 * kTileM;
+constexpr int kCoopLdsFloats = 2 * kTileM * kExLd + kCoopWaves * kTileM + 2 * kGammaRow + kZFloats + kTabFloats;
 
 __global__ __launch_bounds__(kCoopThreads, 2) void card_sample_coop_kernel(const RunParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const ex = lds;                                         // 2 exchange tiles [32][132]
     float* const red = ex + 2 * kTileM * kExLd;                    // [4][32] lin4 partial sums
     float* const gsl = red + kCoopWaves * kTileM;                  // 2 gamma rows
-    float* const tab = gsl + 2 * kGammaRow;                        // small tables
+    float* const zb = gsl + 2 * kGammaRow;                         // the tile's normals for 32 draws
+    float* const tab = zb + kZFloats;                              // small tables
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -495,16 +501,20 @@ __global__ __launch_bounds__(kCoopThreads, 2) void card_sample_coop_kernel(const
             for (int e = 0; e < 4; ++e)
                 c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], static_feature(1 + 8 * q + 2 * e + hh), c1, 0, 0, 0);
         }
-        float zc[4];
-        uint32_t zblock = 0xFFFFFFFFu;
+        // zfill(d): make sure zb holds the group of 32 draws that contains draw d (workgroup-uniform; the reads of a draw
+        // come after the next barrier, and a refill is at least two barriers behind the last read of the old group)
+        int zgrp = -1;
+        auto zfill = [&](int d) {
+            if (p.noise || (d >> 5) == zgrp) return;
+            zgrp = d >> 5;
+            float zz[4];
+            philox_normal4(p.seed, elem, (uint32_t)(8 * zgrp + 2 * w + hh), zz);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) zb[((2 * w + hh) * 4 + j) * kTileM + m] = zz[j];
+        };
         auto draw = [&](int d) -> float {
             if (p.noise) return p.noise[(long long)(d - draw0) * p.N + rc];
-            const uint32_t blk = (uint32_t)d >> 2;
-            if (blk != zblock) {
-                philox_normal4(p.seed, elem, blk, zc);
-                zblock = blk;
-            }
-            return pick4(zc, d & 3);
+            return zb[(((d >> 2) & 7) * 4 + (d & 3)) * kTileM + m];
         };
         auto store_state = [&](int s, float v) {
             long long slot;
@@ -513,6 +523,10 @@ __global__ __launch_bounds__(kCoopThreads, 2) void card_sample_coop_kernel(const
             else return;
             if (slot >= 0 && valid && hh == 0 && w == 0) p.out[slot * p.N + row] = v;
         };
+        if (!p.y_init) zfill(0);
+        // gamma row of the first step (the previous tile's last reads of either buffer are behind its barriers)
+        for (int i = tid; i < kGammaRow; i += kCoopThreads) gsl[gcur * kGammaRow + i] = p.gtab[(long long)p.t_hi * kGammaRow + i];
+        __syncthreads();
         float y;
         if (p.y_init) {
             y = p.y_init[rc];
@@ -520,9 +534,6 @@ __global__ __launch_bounds__(kCoopThreads, 2) void card_sample_coop_kernel(const
             y = draw(0) + mu;                                 // diffusion_utils.py:109-110
             store_state(0, y);
         }
-        // gamma row of the first step (the previous tile's last reads of either buffer are behind its barriers)
-        for (int i = tid; i < kGammaRow; i += kCoopThreads) gsl[gcur * kGammaRow + i] = p.gtab[(long long)p.t_hi * kGammaRow + i];
-        __syncthreads();
 
         // publish this wave's 32 x 32 block of activations / gather all 128 features of the tile's chains
         auto publish = [&](const f32x16& a, int buf) {
@@ -549,13 +560,15 @@ __global__ __launch_bounds__(kCoopThreads, 2) void card_sample_coop_kernel(const
             const bool more = t > p.t_lo;
             f32x4 gn = {0.f, 0.f, 0.f, 0.f};
             if (more && tid < kGammaRow / 4) gn = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(t - 1) * kGammaRow + tid * 4);
-            const float z = t >= 1 && !p.eps_only ? draw(T - t) : 0.0f;
+            const bool noisy = t >= 1 && !p.eps_only;
+            if (noisy) zfill(T - t);
             const float* const gl = gsl + gcur * kGammaRow + 4 * hh;
 
             f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a10, hh == 0 ? y : 0.0f, c1, 0, 0, 0);
             epilogue_tile(acc, gl, w);
             publish(acc, 0);
             __syncthreads();
+            const float z = noisy ? draw(T - t) : 0.0f;
             acc = hidden(A2, 0, 1, gl);
             publish(acc, 1);
             __syncthreads();
@@ -610,7 +623,7 @@ __global__ __launch_bounds__(kCoopThreads, 2) void card_sample_coop_kernel(const
 // un-sliced paired form.
 // ------------------------------------------------------------------------------------------------
 constexpr int kCoop2Threads = 2 * kCoopThreads;
-constexpr int kHalfLdsFloats = 2 * kTileM * kExLd + kCoopWaves * kTileM + 2 * kGammaRow;
+constexpr int kHalfLdsFloats = 2 * kTileM * kExLd + kCoopWaves * kTileM + 2 * kGammaRow + kZFloats;
 constexpr int kCoop2LdsFloats = 2 * kHalfLdsFloats + kTabFloats;
 
 __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop2_kernel(const RunParams p) {
@@ -623,6 +636,7 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop2_kernel(con
     float* const ex = lds + half * kHalfLdsFloats;                 // 2 exchange tiles [32][132]
     float* const red = ex + 2 * kTileM * kExLd;                    // [4][32] lin4 partial sums
     float* const gsl = red + kCoopWaves * kTileM;                  // 2 gamma rows
+    float* const zb = gsl + 2 * kGammaRow;                         // the tile's normals for 32 draws (see kZFloats)
     float* const tab = lds + 2 * kHalfLdsFloats;                   // small tables, shared by the halves
     const int m = lane & 31, hh = lane >> 5;
     for (int i = tid; i < kTabFloats; i += kCoop2Threads) tab[i] = p.wpk[kOffB + i];
@@ -694,16 +708,18 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop2_kernel(con
                 c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], static_feature(1 + 8 * q + 2 * e + hh), c1, 0, 0, 0);
         }
     }
-    float zc[4];
-    uint32_t zblock = 0xFFFFFFFFu;
+    int zgrp = -1;
+    auto zfill = [&](int d) {                    // uniform over the half; see card_sample_coop_kernel
+        if (p.noise || (d >> 5) == zgrp) return;
+        zgrp = d >> 5;
+        float zz[4];
+        philox_normal4(p.seed, elem, (uint32_t)(8 * zgrp + 2 * w + hh), zz);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) zb[((2 * w + hh) * 4 + j) * kTileM + m] = zz[j];
+    };
     auto draw = [&](int d) -> float {
         if (p.noise) return p.noise[(long long)(d - draw0) * p.N + rc];
-        const uint32_t blk = (uint32_t)d >> 2;
-        if (blk != zblock) {
-            philox_normal4(p.seed, elem, blk, zc);
-            zblock = blk;
-        }
-        return pick4(zc, d & 3);
+        return zb[(((d >> 2) & 7) * 4 + (d & 3)) * kTileM + m];
     };
     auto store_state = [&](int s, float v) {
         long long slot;
@@ -714,6 +730,11 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop2_kernel(con
     };
     float y = 0.0f;
     if (active) {
+        if (first_seg && !p.y_init) zfill(0);
+        for (int i = htid; i < kGammaRow; i += kCoopThreads) gsl[i] = p.gtab[(long long)th * kGammaRow + i];
+    }
+    __syncthreads();
+    if (active) {
         if (!first_seg) {
             y = p.ybuf[rc];
         } else if (p.y_init) {
@@ -722,9 +743,7 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop2_kernel(con
             y = draw(0) + mu;                                 // diffusion_utils.py:109-110
             store_state(0, y);
         }
-        for (int i = htid; i < kGammaRow; i += kCoopThreads) gsl[i] = p.gtab[(long long)th * kGammaRow + i];
     }
-    __syncthreads();
     int gcur = 0;
 
     auto publish = [&](const f32x16& a, int buf) {
@@ -757,13 +776,14 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop2_kernel(con
         const float* const gl = gsl + gcur * kGammaRow + 4 * hh;
         if (on) {
             if (more && htid < kGammaRow / 4) gn = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(t - 1) * kGammaRow + htid * 4);
-            z = t >= 1 && !p.eps_only ? draw(T - t) : 0.0f;
+            if (t >= 1 && !p.eps_only) zfill(T - t);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a10, hh == 0 ? y : 0.0f, c1, 0, 0, 0);
             epilogue_tile(acc, gl, w);
             publish(acc, 0);
         }
         __syncthreads();
         if (on) {
+            z = t >= 1 && !p.eps_only ? draw(T - t) : 0.0f;
             acc = hidden(A2, 0, 1, gl);
             publish(acc, 1);
         }
@@ -817,12 +837,13 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop2_kernel(con
 // k in index order (tools/ubench/mfma_order.hip: 0 mismatches against a host fmaf chain), so it is enough to feed the
 // input features of every layer in the same order.  The 32-chain kernels consume (f, f + 4) per MFMA for
 // f = 8i + e, i = 0..15, e = 0..3; here MFMA s (k = lane group g) takes feature 8(s>>1) + 2(s&1) + (g>>1) + 4(g&1).
-// The activation exchange tile is stored in that order (slot 16a + 4g + j for MFMA s = 4a + j), so a lane still fetches
+// The activation exchange tile is stored in that order (float 64(g&1) + 8a + 4(g>>1) + j for MFMA s = 4a + j), so a lane still fetches
 // the B operands of four MFMAs with one ds_read_b128; lin4's partial sums follow the other kernels' association
 // (two 16-feature chains per wave handed between lane groups with __shfl_xor, then added).
 // ------------------------------------------------------------------------------------------------
 constexpr int kT16 = 16;
-constexpr int kHalf16LdsFloats = 2 * kT16 * kExLd + kCoopWaves * kT16 + 2 * kGammaRow;
+constexpr int kZ16Floats = 16 * 4 * kT16;              // [block & 15][draw & 3][chain]: 64 draws of the tile's 16 chains
+constexpr int kHalf16LdsFloats = 2 * kT16 * kExLd + kCoopWaves * kT16 + 2 * kGammaRow + kZ16Floats;
 constexpr int kCoop16LdsFloats = 2 * kHalf16LdsFloats + kTabFloats;
 constexpr int kImg16Floats = 2 * kH * kH;                 // W2 | W3 in 16x16x4 fragment order
 
@@ -861,6 +882,7 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
     float* const ex = lds + half * kHalf16LdsFloats;               // 2 exchange tiles [16][132], permuted feature order
     float* const red = ex + 2 * kT16 * kExLd;                      // [4][16] lin4 partial sums
     float* const gsl = red + kCoopWaves * kT16;                    // 2 gamma rows
+    float* const zb = gsl + 2 * kGammaRow;                         // the tile's normals for 64 draws
     float* const tab = lds + 2 * kHalf16LdsFloats;
     const int n = lane & 15, g = lane >> 4;
     for (int i = tid; i < kTabFloats; i += kCoop2Threads) tab[i] = p.wpk[kOffB + i];
@@ -906,11 +928,17 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
     float a10[2];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) a10[mb] = g == 0 ? tab[(kOffW1 - kOffB) + 32 * w + 16 * mb + n] : 0.0f;
-    // publish: features 32w + 16mb + 4g + r go to slots 16(2w + mb) + 4(g&1) + 2(g>>1) + {0, 8, 1, 9}[r].  Lanes l and
-    // l + 32 (groups g and g + 2) first trade halves (v_permlane32_swap), so that each writes ONE aligned b128 -- four
-    // slots of its own and its partner's -- instead of two b64 (which conflict two-way: rows n and n + 8 share banks)
-    float* const exw = ex + n * kExLd + 32 * w + 4 * (g & 1) + 8 * (g >> 1);
-    const float* const exr = ex + n * kExLd + 4 * g;                               // + 16a: B operands of MFMAs 4a .. 4a+3
+    // Exchange tile, row n = chain: the four B operands (j = 0..3) that lane group gc consumes for MFMAs 4a .. 4a + 3 sit
+    // at float 64 (gc & 1) + 8a + 4 (gc >> 1) + j.  A ds_read_b128 is served in 16-lane groups that hold every chain n
+    // once, from lane groups {0, 1} or {2, 3}: the two groups of a pair are 64 floats = one whole bank row apart, so the
+    // 16-byte slot is n + 2a + (gc >> 1) mod 16 -- conflict-free (the first layout, 16a + 4gc + j, put lanes (gc, n) and
+    // (gc + 1, n - 1) on one slot: 27 % of the LDS-array cycles were conflict cycles, profiles/r02_pmc_small_batch.jsonl).
+    // publish: accumulator register r of block mb is feature 32w + 16mb + 4g + r = the operand of MFMA s = 4a + j for
+    // lane group gc with a = 2w + mb, gc = (g & 1) + 2 (r >> 1) ... after lanes l and l + 32 (groups g and g + 2) have
+    // traded halves (v_permlane32_swap) each lane holds j = 0..3 of ONE consumer group gc = g and writes one aligned
+    // b128 (8 consecutive lanes = 8 consecutive chains at one column: conflict-free)
+    float* const exw = ex + n * kExLd + 64 * (g & 1) + 4 * (g >> 1) + 16 * w;      // + 8 mb
+    const float* const exr = ex + n * kExLd + 64 * (g & 1) + 4 * (g >> 1);         // + 8a: B operands of MFMAs 4a .. 4a+3
     const int T = p.T;
     const int draw0 = p.y_init ? (T - p.t_hi) : 0;
     const int slot_base = draw0;
@@ -947,16 +975,20 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
             }
         }
     }
-    float zc[4];
-    uint32_t zblock = 0xFFFFFFFFu;
+    // the 16 (wave, lane group) copies of a chain draw 16 different blocks: one generator call per lane covers 64
+    // timesteps of the tile (see kZFloats above)
+    int zgrp = -1;
+    auto zfill = [&](int d) {                    // uniform over the half
+        if (p.noise || (d >> 6) == zgrp) return;
+        zgrp = d >> 6;
+        float zz[4];
+        philox_normal4(p.seed, elem, (uint32_t)(16 * zgrp + 4 * w + g), zz);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) zb[((4 * w + g) * 4 + j) * kT16 + n] = zz[j];
+    };
     auto draw = [&](int d) -> float {
         if (p.noise) return p.noise[(long long)(d - draw0) * p.N + rc];
-        const uint32_t blk = (uint32_t)d >> 2;
-        if (blk != zblock) {
-            philox_normal4(p.seed, elem, blk, zc);
-            zblock = blk;
-        }
-        return pick4(zc, d & 3);
+        return zb[(((d >> 2) & 15) * 4 + (d & 3)) * kT16 + n];
     };
     auto store_state = [&](int s, float v) {
         long long slot;
@@ -967,6 +999,11 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
     };
     float y = 0.0f;
     if (active) {
+        if (first_seg && !p.y_init) zfill(0);
+        for (int i = htid; i < kGammaRow; i += kCoopThreads) gsl[i] = p.gtab[(long long)th * kGammaRow + i];
+    }
+    __syncthreads();
+    if (active) {
         if (!first_seg) {
             y = p.ybuf[rc];
         } else if (p.y_init) {
@@ -975,9 +1012,7 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
             y = draw(0) + mu;                                 // diffusion_utils.py:109-110
             store_state(0, y);
         }
-        for (int i = htid; i < kGammaRow; i += kCoopThreads) gsl[i] = p.gtab[(long long)th * kGammaRow + i];
     }
-    __syncthreads();
     int gcur = 0;
 
     auto publish = [&](const f32x4 (&a)[2], int buf) {
@@ -991,7 +1026,7 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
             asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1"
                          : "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1));
             const f32x4 v = {x0, y0, x1, y1};
-            *reinterpret_cast<f32x4*>(exw + buf * kT16 * kExLd + 16 * mb) = v;
+            *reinterpret_cast<f32x4*>(exw + buf * kT16 * kExLd + 8 * mb) = v;
         }
     };
     auto hidden = [&](const float (&A)[64], int buf, int layer, const float* gl, f32x4 (&acc)[2]) {
@@ -999,7 +1034,7 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
         for (int mb = 0; mb < 2; ++mb) acc[mb] = lds4(tb + layer * kH + 16 * mb);
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
-            const f32x4 h = lds4(exr + buf * kT16 * kExLd + 16 * a);
+            const f32x4 h = lds4(exr + buf * kT16 * kExLd + 8 * a);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[4 * a + e], h[e], acc[0], 0, 0, 0);
@@ -1019,7 +1054,7 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
         const float* const gl = gsl + gcur * kGammaRow + 4 * g;
         if (on) {
             if (more && htid < kGammaRow / 4) gn = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(t - 1) * kGammaRow + htid * 4);
-            z = t >= 1 && !p.eps_only ? draw(T - t) : 0.0f;
+            if (t >= 1 && !p.eps_only) zfill(T - t);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a10[mb], g == 0 ? y : 0.0f, c1[mb], 0, 0, 0);
             epilogue16(acc, gl + 32 * w);
@@ -1027,6 +1062,7 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
         }
         __syncthreads();
         if (on) {
+            z = t >= 1 && !p.eps_only ? draw(T - t) : 0.0f;
             hidden(A2, 0, 1, gl, acc);
             publish(acc, 1);
         }
