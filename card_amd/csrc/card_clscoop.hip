@@ -150,7 +150,7 @@ __device__ __forceinline__ void epilogue_bn(f32x16& acc, const float* gl, const 
 // segments land in different slices in order (n_tiles >= slots per slice when slicing is on), stream order is the only
 // synchronisation, and a chain's state travels through ybuf.  The arithmetic per chain and timestep does not depend
 // on G or on the slicing: results are bit-identical to the one-tile, un-sliced form.
-template <int G, int FORM = 0>
+template <int G, int FORM = 0, bool MULTI = false>
 __global__ __launch_bounds__(kThreads, FORM >= 1 ? 2 : 1) void card_sample_cls_coop_kernel(const ClsCoopParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using L = ClsLds<FORM>;
@@ -209,6 +209,13 @@ __global__ __launch_bounds__(kThreads, FORM >= 1 ? 2 : 1) void card_sample_cls_c
     const long long NC = p.N * C;
     const int n_steps = p.t_hi - p.t_lo + 1;
 
+    // ---- rounds (MULTI): a workgroup keeps its weight fragments and walks the slots q0 + (blockIdx.x + round * gridDim.x) * g_eff + g.
+    // One round when the host launches a workgroup per slot (the time-sliced loops: MULTI = false, the loop below is then
+    // straight-line code and costs the hot form no registers); several when a short call -- the
+    // reference's per-timestep p_sample (classification/card_classification.py:645-653, :665-670), card_eps_theta -- has more
+    // tiles than the CUs hold workgroups: the 128 KB of W2 / W3 fragments are then read once per resident workgroup, not
+    // once per tile.
+    for (long long first = p.q0 + (long long)blockIdx.x * p.g_eff; first < p.q1; first += (long long)gridDim.x * p.g_eff) {
     // ---- the G tile positions of this workgroup
     float* ex[G]; float* ys[G]; float* red[G]; float* gsl[G]; float* zbuf[G]; float* c1l[G];
     float* exw[G]; const float* exr[G]; float* ysw[G]; const float* ysr[G];
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(kThreads, FORM >= 1 ? 2 : 1) void card_sample_cls_c
         exr[g] = ex[g] + m * kExLd + 4 * hh;
         ysw[g] = ys[g] + m * YL + c0;
         ysr[g] = ys[g] + m * YL + 4 * hh;
-        const long long q = p.q0 + (long long)blockIdx.x * p.g_eff + g;
+        const long long q = first + g;
         active[g] = g < p.g_eff && q < p.q1;
         const long long tile = active[g] ? q % n_tiles : 0;
         const int seg = active[g] ? (int)(q / n_tiles) : 0;
@@ -555,6 +562,9 @@ __global__ __launch_bounds__(kThreads, FORM >= 1 ? 2 : 1) void card_sample_cls_c
                 if (c0 + k < C) p.out[row[g] * C + c0 + k] = yv[g][k];
         }
     }
+    if constexpr (!MULTI) break;
+    __syncthreads();        // (a workgroup without a timestep in this round has passed no barrier since its prologue)
+    }   // rounds
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -627,6 +637,8 @@ int clscoop_create(card_sampler* s, const card_model_desc* d, hipStream_t stream
     HIP_TRY(hipFuncSetAttribute((const void*)card_sample_cls_coop_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats(2) * sizeof(float))));
     HIP_TRY(hipFuncSetAttribute((const void*)card_sample_cls_coop_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats(1) * sizeof(float))));
     HIP_TRY(hipFuncSetAttribute((const void*)card_sample_cls_coop_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats(1, 2) * sizeof(float))));
+    HIP_TRY(hipFuncSetAttribute((const void*)card_sample_cls_coop_kernel<1, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats(1) * sizeof(float))));
+    HIP_TRY(hipFuncSetAttribute((const void*)card_sample_cls_coop_kernel<1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats(1, 2) * sizeof(float))));
     s->coop_blocks = 1;
     cls_pack_hidden_kernel<<<kF * kF / 256, 256, 0, stream>>>(d->W[1], s->wpk);
     cls_pack_hidden_kernel<<<kF * kF / 256, 256, 0, stream>>>(d->W[2], s->wpk + kF * kF);
@@ -678,8 +690,13 @@ int clscoop_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     auto launch = [&](int g_eff, long long grid) -> int {
         if (pair && g_eff == 2) {
             p.g_eff = 1;
-            const dim3 pgrid((unsigned)(p.q1 - p.q0));
-            if (compact) card_sample_cls_coop_kernel<1, 2><<<pgrid, dim3(kThreads), lds_floats(1, 2) * sizeof(float), stream>>>(p);
+            // (at most the workgroups the chip holds at once, two per CU: the kernel walks the remaining slots in rounds)
+            const long long pn = p.q1 - p.q0 < 2LL * s->num_cu ? p.q1 - p.q0 : 2LL * s->num_cu;
+            const dim3 pgrid((unsigned)pn);
+            const bool multi = p.q1 - p.q0 > pn;
+            if (compact && multi) card_sample_cls_coop_kernel<1, 2, true><<<pgrid, dim3(kThreads), lds_floats(1, 2) * sizeof(float), stream>>>(p);
+            else if (compact) card_sample_cls_coop_kernel<1, 2><<<pgrid, dim3(kThreads), lds_floats(1, 2) * sizeof(float), stream>>>(p);
+            else if (multi) card_sample_cls_coop_kernel<1, 1, true><<<pgrid, dim3(kThreads), lds_floats(1) * sizeof(float), stream>>>(p);
             else card_sample_cls_coop_kernel<1, 1><<<pgrid, dim3(kThreads), lds_floats(1) * sizeof(float), stream>>>(p);
             HIP_TRY(hipGetLastError());
             return CARD_OK;

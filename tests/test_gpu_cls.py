@@ -420,6 +420,64 @@ def test_per_timestep_shim_loop_equals_fused_loop_and_pins_nothing():
     assert ref() is None and du._tls.ctx.refs is None and du._tls.ctx.keep is None          # released: owns nothing, can never match
 
 
+def test_per_timestep_loop_runs_ahead_and_survives_pattern_breaks(monkeypatch):
+    """The look-ahead of the per-timestep entry points (card_amd/diffusion_utils.py: LOOKAHEAD_MAX_STEPS): the reference's
+    T-call loop (classification/card_classification.py:656-671) issues O(log T) launches instead of T, every state it
+    hands out is bit-equal to the one-launch-per-call result, and a caller that edits y in place, re-feeds an older
+    state, or passes its own noise falls back to its own launch with the same bits."""
+    from card_amd import diffusion_utils as du
+    g = load_golden("cls_mnist_T50")
+    m = RefShapedCls(g["sd"]).to(DEV).eval()
+    T = g["T"]
+    al, om = cuda(g["alphas"]), cuda(g["omabs"])
+    xf, y0 = cuda(g["x_feat"]), cuda(g["y0hat"])
+    yT = card_amd.p_sample_loop(m, xf, y0, y0, T, al, om, seed=5, states=[0])[0]
+
+    def loop(edit_at=None):
+        du._drop_step_ctx()
+        states, cur = [], yT
+        for t in reversed(range(1, T)):
+            cur = card_amd.p_sample(m, xf, cur, y0, y0, t, al, om, seed=5)
+            if t == edit_at:
+                cur.mul_(0.5)                     # in place: the version counter moves, what was computed ahead is stale
+            states.append(cur)
+        states.append(card_amd.p_sample_t_1to0(m, xf, cur, y0, y0, om))
+        return states
+
+    calls = []
+    real = _lib.lib().card_sampler_run
+
+    def counting(h, a, st):
+        calls.append(1)
+        return real(h, a, st)
+
+    monkeypatch.setattr(du, "LOOKAHEAD_MAX_STEPS", 0)
+    plain = loop()
+    plain_edit = loop(edit_at=T // 2)
+    monkeypatch.setattr(du, "LOOKAHEAD_MAX_STEPS", 16)
+    monkeypatch.setattr(_lib.lib(), "card_sampler_run", counting, raising=False)
+    ahead = loop()
+    n_launches = len(calls)
+    assert n_launches <= 8, n_launches            # 1 + 1 (2) + 1 (4) + 1 (8) + 2 (16, 16) + 1 (the rest) for T = 50
+    assert all(torch.equal(a, b) for a, b in zip(ahead, plain))
+    assert torch.equal(ahead[-1], card_amd.p_sample_loop(m, xf, y0, y0, T, al, om, True, seed=5))
+    calls.clear()
+    ahead_edit = loop(edit_at=T // 2)
+    assert all(torch.equal(a, b) for a, b in zip(ahead_edit, plain_edit))
+    assert n_launches < len(calls) < T            # the edit cost one fresh start of the doubling, not the look-ahead
+    # re-feeding an older state, and explicit noise, run on their own
+    du._drop_step_ctx()
+    a1 = card_amd.p_sample(m, xf, yT, y0, y0, T - 1, al, om, seed=5)
+    a2 = card_amd.p_sample(m, xf, a1, y0, y0, T - 2, al, om, seed=5)         # runs T-2 and T-3
+    again = card_amd.p_sample(m, xf, a1, y0, y0, T - 2, al, om, seed=5)      # not a continuation of a2
+    assert torch.equal(again, a2) and torch.equal(a2, plain[1])
+    z = torch.randn_like(a2)
+    nz = card_amd.p_sample(m, xf, again, y0, y0, T - 3, al, om, noise=z)
+    du._drop_step_ctx()
+    monkeypatch.setattr(du, "LOOKAHEAD_MAX_STEPS", 0)
+    assert torch.equal(nz, card_amd.p_sample(m, xf, again, y0, y0, T - 3, al, om, noise=z))
+
+
 def test_wrapped_models_module_holders_sample_like_the_bare_model():
     """classification/imagenet/main.py:222-237 hands p_sample_loop a DistributedDataParallel / DataParallel wrapper around
     the CARD model (:482, :557); round 2 raised 'does not recognise DistributedDataParallel' there.  The ImageNet head

@@ -30,7 +30,8 @@ class Guided(torch.nn.Module):            # attribute layout of regression/model
 m = Guided(guided_state_dict(x_dim, T)).to(dev).eval()
 alphas, _, omabs = make_schedule("linear", T, 1e-4, 0.02)
 alphas, omabs = alphas.to(dev), omabs.to(dev)
-for rows, nz in ((64, 1000), (64, 200), (256, 1000)):
+ONLY = os.environ.get("DROPIN_ONLY", "")          # "cls128": only the F = 128 classification loops (for rocprofv3 runs)
+for rows, nz in (() if ONLY else ((64, 1000), (64, 200), (256, 1000))):
     g = torch.Generator().manual_seed(0)
     x = torch.randn(rows, x_dim, generator=g).to(dev)
     y0 = torch.randn(rows, 1, generator=g).to(dev)
@@ -79,7 +80,8 @@ def only_y_0(model, x, y_0_hat, y_T_mean, n_steps, alphas, omabs):
     return card_amd.p_sample_t_1to0(model, x, cur_y, y_0_hat, y_T_mean, omabs)
 
 
-for F, C, rows, nz, Tc in ((128, 10, 250, 100, 1000), (128, 10, 1, 32, 1000), (4096, 10, 250, 100, 20)):
+CASES = ((128, 10, 250, 100, 1000), (128, 10, 1, 32, 1000), (4096, 10, 250, 100, 20))
+for F, C, rows, nz, Tc in (CASES[:1] if ONLY == "cls128" else CASES):
     mc = Cls(cls_state_dict(F, C, Tc, 3)).to(dev).eval()
     al, _, om = make_schedule("linear", Tc, 1e-4, 0.02)
     al, om = al.to(dev), om.to(dev)
