@@ -16,7 +16,6 @@ Rank 0 prints ONE JSON line with the driver contract's fields plus `roofline` an
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time
@@ -156,8 +155,6 @@ def main():
     arith = _lib.ARITH_SPLIT_BF16 if a.arith == "split" else _lib.ARITH_F32_MFMA
     if arith == _lib.ARITH_SPLIT_BF16 and not (kind == "guided" and H == 128 and y_dim == 1):
         sys.exit("--arith split is built for the hidden-128 regression sampler")
-    persistent = kind == "guided" and H in (128, 256)     # card_guided.hip / card_stream.hip; otherwise GEMM back end
-    cls_coop = kind == "cls" and H == 128 and y_dim <= 32  # card_clscoop.hip
     x, y0 = x_rows.to(dev), y0_rows.to(dev)
     elem_offset = rank * N * y_dim
     from card_amd.distributed import all_reduce_sums
@@ -209,70 +206,31 @@ def main():
         units = float(N) * T * a.steps * world
         value = units / elapsed
         ev_ms = ev0.elapsed_time(ev1)                      # HIP events on the launch stream, rank 0
-        if persistent:
-            # dominant (only) kernel = card_sample_guided_kernel; launches per step from guided_run()'s chunking
+        # kernel name, launches and executed flops come from the library itself: card_sampler_plan is a dry run of the
+        # dispatch code this call went through (no Python copy of the thresholds / slicing / chunking to drift)
+        pl = sampler.run(x, y0, y0, coef, T, seed=1234, elem_offset=elem_offset, out_mode=_lib.OUT_LAST, n_z=a.nz, arith=arith,
+                         plan=True)
+        kernel, launches = pl["kernel"], pl["launches"] * a.steps
+        if pl["backend"] == 1:
+            kernel += " (+ layer-1 GEMM and head/update launches, all inside the timed region)"
+        assert abs(pl["flops_per_sample_step"] - flops_per_unit) < 0.5, (pl, flops_per_unit)
+        chunk = None
+        if pl["kernel"].startswith("card_sample_guided_kernel"):
+            # chains of one full launch of the persistent kernel (guided_run: CUs x 8 waves x 16 tiles x 32 chains), the key
+            # of the measured-traffic table below
             cu = torch.cuda.get_device_properties(dev).multi_processor_count
-            chunk = cu * WAVES_PER_CU * TILES_PER_WAVE_PER_LAUNCH * TILE_M if H == 128 else cu * 8 * 128   # guided_run / stream_run
-            launches = math.ceil(N / chunk) * a.steps
-            kernel = "card_sample_guided_kernel" if H == 128 else "card_sample_stream_kernel"
-            if arith == _lib.ARITH_SPLIT_BF16:
-                chunk = cu * 96 * 3 * 32                       # split_run(): 96 groups of three 32-chain tiles per CU and launch
-                launches = math.ceil(N / chunk) * a.steps
-                kernel = "card_sample_split_kernel"
-            elif H == 128 and N <= 7 * cu * 32:
-                # guided_run(): small batches run on the cooperative kernels, between one and two tiles per CU time-sliced
-                def slices(tiles, rho):
-                    if not cu < tiles < 2 * cu or T < 64:
-                        return 1
-                    n_single = 2 * cu - tiles
-                    K = math.ceil(tiles / n_single)
-                    S = int(T / (K - 1 + rho) + 0.5)
-                    return K if (K <= 8 and S >= 8 and T - (K - 1) * S >= S) else 1
-                t16, t32 = math.ceil(N / 16), math.ceil(N / 32)
-                if t16 <= 2 * cu - cu // 8:
-                    kernel, launches = "card_sample_coop16_kernel", slices(t16, 1.65) * a.steps
-                elif cu < t32 < 2 * cu:
-                    kernel, launches = "card_sample_coop2_kernel", slices(t32, 1.717) * a.steps
-                else:
-                    kernel, launches = "card_sample_coop_kernel", a.steps
-        elif cls_coop:
-            # clscoop_run(): one launch up to num_cu tiles, else round-robin time slices of num_cu x 2 (tile, segment) slots
-            cu = torch.cuda.get_device_properties(dev).multi_processor_count
-            chunk = None
-            tiles, P = math.ceil(N / 32), 2 * cu
-            n_seg = 1
-            if tiles > P and T >= 64:
-                n_seg = min(range(1, 17), key=lambda ns: (math.ceil(tiles * ns / P) * (math.ceil(T / ns) + 4.0)) if T // ns >= 32 else float("inf"))
-            per = P if n_seg > 1 else min(tiles, P)
-            launches = (1 if tiles <= cu else math.ceil(tiles * n_seg / per)) * a.steps
-            kernel = "card_sample_cls_coop_kernel"
-        else:
-            # GEMM back end: a timestep is 3 GEMM launches (layer 1 over the padded state matrix, two F x F) + one VALU launch
-            # (lin4 + posterior update; a 4th GEMM + an update launch above 32 classes) per chunk of chains; the two F x F
-            # wide_gemm_kernel<EPI_SOFTPLUS> launches carry > 95 % of the flops.  `achieved` below still divides the
-            # algorithmic flops by the WHOLE timed region (every launch), so it is a lower bound for that kernel.
-            chunk = None
-            launches = 2 * T * a.steps
-            kernel = "wide_gemm_kernel<EPI_SOFTPLUS> (+ layer-1 GEMM and head/update launches, all inside the timed region)"
+            chunk = cu * WAVES_PER_CU * TILES_PER_WAVE_PER_LAUNCH * TILE_M
         avg_launch_ms = ev_ms / launches
         achieved = (float(N) * T * a.steps * flops_per_unit) / (ev_ms * 1e-3) / 1e12
         # flops the kernels actually issue per sample-step (`achieved` prices the ALGORITHMIC count of SURVEY.md 8d, which
-        # the hoisted layer 1 undercuts -- on the Year shape by 26 % -- and K / class padding overshoots)
-        if persistent and H == 128:
-            nqs = (d_in - 1 + 7) // 8
-            executed = 2 * H * (2 * H) + 2 * H * 2 + 2 * H + 2 * H * 8 * nqs / T     # layers 2-3, K=2 update of layer 1, lin4 (VALU), hoist / T
-        elif persistent:
-            ks1 = next(k for k in (2, 4, 8, 16, 24) if (d_in + 3) // 4 <= k)
-            executed = 2 * H * (4 * ks1 + 2 * H) + 2 * H                              # card_stream.hip: layer 1 on MFMA every step, K padded
-        elif cls_coop:
-            executed = 2 * H * (8 * ((y_dim + 7) // 8) + 2 * H + 32)                  # card_clscoop.hip: y_t columns in 8s, lin4 as a 32-class MFMA tile
-        else:
-            head = y_dim if y_dim <= 32 else 128 * ((y_dim + 127) // 128)                      # fused VALU head, or a GEMM padded to 128 columns
-            executed = 2 * H * (32 * ((d_in + 31) // 32) + 2 * H + head)                        # card_wide.hip: layer-1 K padded to 32s
+        # the hoisted layer 1 undercuts -- on the Year shape by 26 % -- and K / class padding overshoots): from the plan
+        executed = pl["flops_executed_per_sample_step"]
+        if arith == _lib.ARITH_SPLIT_BF16:
+            executed = 2 * H * (2 * H) + 2 * H * 2 + 2 * H        # (the fp32-equivalent count; the bf16 flops are priced below)
         achieved_exec = achieved * executed / flops_per_unit
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if persistent and os.path.exists(tpath):
+        if chunk is not None and os.path.exists(tpath):
             # measured for ONE full-size launch of the same shape (tools/profile_pmc.sh); valid when this run's
             # launches are that size too
             for tj in json.load(open(tpath)).get("entries", []):
@@ -298,7 +256,7 @@ def main():
         if arith == _lib.ARITH_SPLIT_BF16:
             # opt-in arithmetic, not the headline: the two hidden layers run as 6 bf16 MFMAs per 16-deep k-step, so the
             # matrix pipe that bounds this kernel is the bf16 one; `achieved` = the bf16 flops it issues
-            ex_bf16 = 6 * 2 * H * (2 * H)
+            ex_bf16 = pl["flops_executed_per_sample_step"]
             ach = (float(N) * T * a.steps * ex_bf16) / (ev_ms * 1e-3) / 1e12
             out["arith"] = "split_bf16 (CARD_ARITH_SPLIT_BF16: fp32 operands cut exactly into 3 bf16 parts, fp32 accumulation)"
             out["roofline"].update({"achieved": ach, "peak": PEAK_BF16_MATRIX_TFLOPS, "frac": ach / PEAK_BF16_MATRIX_TFLOPS,

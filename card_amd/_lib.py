@@ -15,7 +15,7 @@ EXPORTS = (
     "card_version", "card_last_error", "card_make_coef_table", "card_sampler_create", "card_sampler_destroy",
     "card_sampler_run", "card_sampler_workspace_bytes", "card_eps_theta", "card_q_sample", "card_philox_normal",
     "card_regression_row_metrics", "card_classification_row_metrics", "card_sampler_run_static", "card_content_hash",
-    "card_fphi_create", "card_fphi_destroy", "card_fphi_forward",
+    "card_fphi_create", "card_fphi_destroy", "card_fphi_forward", "card_sampler_plan",
 )
 FPHI_MAX_LAYERS, FPHI_MAX_WIDTH = 8, 1024
 STATIC_SCRATCH_BYTES = 32 << 20
@@ -39,6 +39,13 @@ class RunArgs(C.Structure):
         ("noise", _fp), ("seed", C.c_uint64), ("elem_offset", C.c_uint64), ("out", _fp),
         ("out_mode", C.c_int32), ("n_z", C.c_int32), ("state_slot", _fp), ("workspace", _fp), ("workspace_bytes", C.c_uint64),
         ("fphi", _fp), ("fphi_out", _fp), ("arith", C.c_int32), ("reserved0", C.c_int32),
+    ]
+
+
+class Plan(C.Structure):
+    _fields_ = [
+        ("struct_bytes", C.c_int32), ("backend", C.c_int32), ("launches", C.c_int32), ("dominant_launches", C.c_int32),
+        ("kernel", C.c_char * 96), ("flops_per_sample_step", C.c_double), ("flops_executed_per_sample_step", C.c_double),
     ]
 
 
@@ -94,6 +101,7 @@ def lib():
     L.card_sampler_destroy.restype = None
     L.card_sampler_run.argtypes = [C.c_void_p, C.POINTER(RunArgs), C.c_void_p]
     L.card_sampler_run_static.argtypes = [C.c_void_p, C.POINTER(RunArgs), C.c_void_p]
+    L.card_sampler_plan.argtypes = [C.c_void_p, C.POINTER(RunArgs), C.POINTER(Plan)]
     L.card_content_hash.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32, C.c_void_p, C.c_void_p]
     L.card_sampler_workspace_bytes.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_uint64)]
     L.card_eps_theta.argtypes = [C.c_void_p, _fp, _fp, _fp, C.c_int64, C.c_int32, _fp, _fp, C.c_uint64, C.c_void_p]

@@ -107,6 +107,33 @@ static int static_scratch(int device, void** out) {
     return CARD_OK;
 }
 
+// One environment variable per back end, comma-separated tokens (card_internal.h: CardTune); the digits 0 / 2 of earlier
+// rounds still mean off / force.
+static bool env_has(const char* name, const char* token, char digit = 0) {
+    const char* v = getenv(name);
+    if (!v) return false;
+    if (digit && v[0] == digit && (v[1] == 0 || v[1] == ',')) return true;
+    const size_t n = strlen(token);
+    for (const char* q = v; (q = strstr(q, token)) != nullptr; q += n)
+        if ((q == v || q[-1] == ',') && (q[n] == 0 || q[n] == ',')) return true;
+    return false;
+}
+
+void card_tune_from_env(CardTune* t) {
+    memset(t, 0, sizeof(*t));
+    t->coop_off = env_has("CARD_AMD_COOP", "off", '0');
+    t->coop_force = env_has("CARD_AMD_COOP", "force", '2');
+    t->coop_no16 = env_has("CARD_AMD_COOP", "no16");
+    t->coop_no2 = env_has("CARD_AMD_COOP", "no2");
+    t->stream_off = env_has("CARD_AMD_STREAM", "off", '0');
+    t->stream_big = env_has("CARD_AMD_STREAM", "big");
+    t->cls_off = env_has("CARD_AMD_CLSCOOP", "off", '0');
+    t->cls_noslice = env_has("CARD_AMD_CLSCOOP", "noslice");
+    t->wide_gemmhead = env_has("CARD_AMD_WIDE", "gemmhead");
+    t->wide_notail = env_has("CARD_AMD_WIDE", "notail");
+    t->arith_split = env_has("CARD_AMD_ARITH", "split");
+}
+
 int card_fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -173,7 +200,9 @@ extern "C" CARD_API int card_sampler_create(const card_model_desc* d, void* stre
     }
     // the persistent kernel is built for the reference's regression network (H = 128, y_dim = 1); every other
     // shape (classification heads, wider or multi-output regression nets) streams through the GEMM back end
-    s->backend = (d->variant == CARD_VARIANT_GUIDED && d->hidden == 128 && d->y_dim == 1) ? 0 : (stream_supports(d, s->d_in) ? 2 : (clscoop_supports(d) ? 3 : 1));
+    card_tune_from_env(&s->tune);      // the only place the library reads the environment
+    s->backend = (d->variant == CARD_VARIANT_GUIDED && d->hidden == 128 && d->y_dim == 1) ? 0
+                 : (stream_supports(d, s->d_in, s->tune) ? 2 : (clscoop_supports(d, s->tune) ? 3 : 1));
     const int rc = s->backend == 0 ? guided_create(s, d, (hipStream_t)stream_)
                  : s->backend == 2 ? stream_create(s, d, (hipStream_t)stream_)
                  : s->backend == 3 ? clscoop_create(s, d, (hipStream_t)stream_) : wide_create(s, d, (hipStream_t)stream_);
@@ -202,7 +231,8 @@ extern "C" CARD_API int card_sampler_workspace_bytes(const card_sampler* s, int6
 
 // shared body of card_sampler_run / card_sampler_run_static: `lib_scratch` != NULL replaces every scratch buffer a
 // back end would otherwise use (the sampler's own per-wave slots, the caller's workspace)
-static int sampler_run(const card_sampler* s, const card_run_args* a, void* stream, void* lib_scratch, unsigned long long lib_scratch_bytes) {
+static int sampler_run(const card_sampler* s, const card_run_args* a, void* stream, void* lib_scratch, unsigned long long lib_scratch_bytes,
+                       CardPlanRec* plan = nullptr) {
     if (!s || !a) return fail(CARD_E_INVALID, "card_sampler_run: null argument");
     if (a->struct_bytes != (int32_t)sizeof(card_run_args))
         return fail(CARD_E_INVALID, "card_sampler_run: struct_bytes %d != %zu", a->struct_bytes, sizeof(card_run_args));
@@ -227,7 +257,8 @@ static int sampler_run(const card_sampler* s, const card_run_args* a, void* stre
             return fail(CARD_E_INVALID, "card_sampler_run: f_phi produces %d outputs, the sampler's y_dim is %d", fphi_out_dim(a->fphi), s->y_dim);
         if (s->cat_x && fphi_in_dim(a->fphi) != s->x_dim)
             return fail(CARD_E_INVALID, "card_sampler_run: f_phi reads %d features, eps_theta's x has %d", fphi_in_dim(a->fphi), s->x_dim);
-        if (int rc = fphi_forward(a->fphi, a->x, a->N / (a->n_z > 1 ? a->n_z : 1), a->fphi_out, (hipStream_t)stream)) return rc;
+        if (!card_plan_note(plan, "fphi_forward_kernel", false))
+            if (int rc = fphi_forward(a->fphi, a->x, a->N / (a->n_z > 1 ? a->n_z : 1), a->fphi_out, (hipStream_t)stream)) return rc;
         y0hat = a->fphi_out;
         if (!ytmean) ytmean = a->fphi_out;
     }
@@ -251,6 +282,7 @@ static int sampler_run(const card_sampler* s, const card_run_args* a, void* stre
     if (lib_scratch) {
         r.workspace = lib_scratch; r.workspace_bytes = lib_scratch_bytes; r.lib_scratch = 1;
     }
+    r.plan = plan;
     return s->backend == 0 ? guided_run(s, r, (hipStream_t)stream)
          : s->backend == 2 ? stream_run(s, r, (hipStream_t)stream)
          : s->backend == 3 ? clscoop_run(s, r, (hipStream_t)stream) : wide_run(s, r, (hipStream_t)stream);
@@ -258,6 +290,26 @@ static int sampler_run(const card_sampler* s, const card_run_args* a, void* stre
 
 extern "C" CARD_API int card_sampler_run(const card_sampler* s, const card_run_args* a, void* stream) {
     return sampler_run(s, a, stream, nullptr, 0);
+}
+
+extern "C" CARD_API int card_sampler_plan(const card_sampler* s, const card_run_args* a, card_plan* out) {
+    if (!s || !a || !out) return fail(CARD_E_INVALID, "card_sampler_plan: null argument");
+    if (out->struct_bytes != (int32_t)sizeof(card_plan))
+        return fail(CARD_E_INVALID, "card_sampler_plan: struct_bytes %d != %zu", out->struct_bytes, sizeof(card_plan));
+    CardPlanRec rec;
+    memset(&rec, 0, sizeof(rec));
+    if (int rc = sampler_run(s, a, nullptr, nullptr, 0, &rec)) return rc;
+    memset(out, 0, sizeof(*out));
+    out->struct_bytes = (int32_t)sizeof(card_plan);
+    out->backend = s->backend;
+    out->launches = rec.launches;
+    out->dominant_launches = rec.dominant_launches;
+    memcpy(out->kernel, rec.kernel, sizeof(out->kernel));
+    const double H = s->hidden;
+    out->flops_per_sample_step = s->variant == CARD_VARIANT_LINEAR_HADAMARD ? 2.0 * H * (s->d_in + H + s->y_dim)
+                                                                           : 2.0 * H * (s->d_in + 2.0 * H + s->y_dim);
+    out->flops_executed_per_sample_step = rec.executed;
+    return CARD_OK;
 }
 
 extern "C" CARD_API int card_sampler_run_static(const card_sampler* s, const card_run_args* a, void* stream) {

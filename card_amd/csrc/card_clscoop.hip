@@ -56,9 +56,9 @@ template <int FORM> struct ClsLds {
     static constexpr int tile = EX0 + kExBuf1 + kTileM * YL + 2 * kGRow + Z + C1 + FR1 + FR4 + XF;
 };
 static_assert(ClsLds<0>::tile == kTileLdsFloats && ClsLds<1>::tile == kTileLdsFloats, "plain layout");
-constexpr int kGmax = 2;                             // tile positions per workgroup
+constexpr int kPerCu = 2;                            // tile positions per CU: two one-tile workgroups (PAIR forms)
 constexpr long long kChunkTiles = 8192;              // tiles per sliced chunk: bounds the hand-over buffer (262 144 chains)
-__host__ __device__ constexpr int lds_floats(int G, int form = 0) { return G * (form == 2 ? ClsLds<2>::tile : kTileLdsFloats) + kTab; }
+__host__ __device__ constexpr int lds_floats(int form) { return (form == 2 ? ClsLds<2>::tile : kTileLdsFloats) + kTab; }
 constexpr int kPrioValu = 3, kPrioMfma = 0;
 
 }  // namespace
@@ -128,34 +128,35 @@ __device__ __forceinline__ void epilogue_bn(f32x16& acc, const float* gl, const 
     __builtin_amdgcn_s_setprio(kPrioMfma);
 }
 
-// One workgroup = four waves (one per SIMD) that advance G tiles in lockstep with ONE copy of the weight fragments in
-// registers.  Two tile positions per CU keep its matrix pipes busy through the barriers and LDS waits of a tile; two forms:
-//   * PAIR (default): two one-tile workgroups per CU (G = 1, __launch_bounds__(256, 2): 256 registers per wave, two waves
-//     per SIMD).  The 128 W2 / W3 fragment registers leave 128 for everything else, so the lin1 and lin4 fragments are not
+// One workgroup = four waves (one per SIMD) that advance one tile with ONE copy of the weight fragments in registers.
+// Two tile positions per CU keep its matrix pipes busy through the barriers and LDS waits of a tile.  Forms:
+//   * ONE (FORM 0): at most num_cu tiles -- one workgroup per CU, up to 512 registers per wave, every fragment held.
+//   * PAIR (FORM 1): two one-tile workgroups per CU (__launch_bounds__(256, 2): 256 registers per wave, two waves per
+//     SIMD).  The 128 W2 / W3 fragment registers leave 128 for everything else, so the lin1 and lin4 fragments are not
 //     held: they are re-read from L2 where they are used (two + four 16-byte loads per lane and timestep, covered by the other
 //     wave of the SIMD), and the Philox block keeps ~29 values in scratch.  The hardware interleaves the two waves of a
 //     SIMD instruction by instruction: every LDS wait, barrier and MFMA -> VALU dependency of one tile is filled with the
-//     other tile's work.  17.6 vs 20.0 us per timestep for the reference's MNIST test minibatch (A/B in one box).
+//     other tile's work.  17.6 vs 20.0 us per timestep for the reference's MNIST test minibatch against round 2's first
+//     form, ONE workgroup advancing two tiles in its one instruction stream (a wave issues in order, so the second tile
+//     filled the first one's waits only as far as the compiler interleaved the two; removed in round 3).
 //   * PAIR compact (FORM 2; up to 16 classes and n_z >= 32, i.e. every F = 128 config of the reference): the LDS layout
 //     ClsLds<2> -- 20-float row pitch, the hoisted layer-1 tile and x_feat as the two columns of the two images a tile
 //     spans -- leaves room for the lin1 / lin4 fragments in LDS: no L2 re-reads, 14 values in scratch; 17.05 us.
-//   * CARD_AMD_CLSCOOP_FORM=two (round 2's first form, kept for A/B): ONE workgroup of up to 512 registers per wave that
-//     advances G = 2 tiles in its one instruction stream; a wave issues in order, so the second tile fills the first
-//     one's waits only as far as the compiler interleaves the two by hand.
 //
 // Time slicing.  A tile is NOT tied to a workgroup for the whole loop: the timesteps of a call are cut into n_seg
 // segments and the (tile, segment) pairs are laid out as slots q = segment * n_tiles + tile; one launch ("slice") runs
-// num_cu * G consecutive slots, one per tile position of every workgroup, so every slice fills the chip whatever
+// num_cu * 2 consecutive slots, one per resident workgroup, so every slice fills the chip whatever
 // n_tiles is (250 images x 100 z = 782 tiles used to cost four rounds of 256 tiles, the last one with 14).  A tile's
 // segments land in different slices in order (n_tiles >= slots per slice when slicing is on), stream order is the only
 // synchronisation, and a chain's state travels through ybuf.  The arithmetic per chain and timestep does not depend
-// on G or on the slicing: results are bit-identical to the one-tile, un-sliced form.
-template <int G, int FORM = 0, bool MULTI = false>
+// on the form or on the slicing: results are bit-identical to the un-sliced ONE form.
+template <int FORM = 0, bool MULTI = false>
 __global__ __launch_bounds__(kThreads, FORM >= 1 ? 2 : 1) void card_sample_cls_coop_kernel(const ClsCoopParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using L = ClsLds<FORM>;
     constexpr bool PAIR = FORM >= 1, COMPACT = FORM == 2;
-    static_assert(!PAIR || G == 1, "the PAIR forms are one-tile workgroups");
+    constexpr int G = 1;      // tile positions per workgroup (round 2's two-tile workgroup lost to the PAIR forms and is gone;
+                              // the per-position arrays below are what is left of it and fold away)
     constexpr int kTileLds = L::tile, YL = L::YL, EX0 = L::EX0;
     constexpr int kC1q = COMPACT ? 8 : 256;                 // distance between a lane's four quads of the hoisted layer-1 tile
     float* const tab = lds + G * kTileLds;
@@ -616,9 +617,8 @@ __global__ void cls_pack_gamma_kernel(const float* g1, const float* g2, const fl
 
 }  // namespace
 
-bool clscoop_supports(const card_model_desc* d) {
-    if (const char* ev = getenv("CARD_AMD_CLSCOOP"))
-        if (ev[0] == '0') return false;                 // A/B: GEMM back end
+bool clscoop_supports(const card_model_desc* d, const CardTune& tune) {
+    if (tune.cls_off) return false;                     // CARD_AMD_CLSCOOP=off: the GEMM back end instead (tests, A/B)
     return d->variant == CARD_VARIANT_BN_HADAMARD && d->hidden == kF && d->x_dim == kF && d->y_dim <= kCmax &&
            d->bn_scale[0] && d->bn_scale[1] && d->bn_scale[2] && d->bn_shift[0] && d->bn_shift[1] && d->bn_shift[2];
 }
@@ -632,13 +632,14 @@ int clscoop_create(card_sampler* s, const card_model_desc* d, hipStream_t stream
     HIP_TRY(hipMalloc(&s->bias, (size_t)kTab * sizeof(float)));
     HIP_TRY(hipMalloc(&s->gtab, (size_t)d->n_embed * kGRow * sizeof(float)));
     HIP_TRY(hipMalloc(&s->ws, (size_t)kChunkTiles * kTileM * C * sizeof(float)));      // chain states between time slices
-    s->lds_bytes = (size_t)lds_floats(kGmax) * sizeof(float);
-    HIP_TRY(hipFuncSetAttribute((const void*)card_sample_cls_coop_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats(1) * sizeof(float))));
-    HIP_TRY(hipFuncSetAttribute((const void*)card_sample_cls_coop_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats(2) * sizeof(float))));
-    HIP_TRY(hipFuncSetAttribute((const void*)card_sample_cls_coop_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats(1) * sizeof(float))));
-    HIP_TRY(hipFuncSetAttribute((const void*)card_sample_cls_coop_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats(1, 2) * sizeof(float))));
-    HIP_TRY(hipFuncSetAttribute((const void*)card_sample_cls_coop_kernel<1, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats(1) * sizeof(float))));
-    HIP_TRY(hipFuncSetAttribute((const void*)card_sample_cls_coop_kernel<1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats(1, 2) * sizeof(float))));
+    s->lds_bytes = (size_t)lds_floats(0) * sizeof(float);
+    {
+        const void* plain[] = {(const void*)card_sample_cls_coop_kernel<0>, (const void*)card_sample_cls_coop_kernel<1>,
+                               (const void*)card_sample_cls_coop_kernel<1, true>};
+        for (const void* fn : plain) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats(0) * sizeof(float))));
+        const void* comp[] = {(const void*)card_sample_cls_coop_kernel<2>, (const void*)card_sample_cls_coop_kernel<2, true>};
+        for (const void* fn : comp) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_floats(2) * sizeof(float))));
+    }
     s->coop_blocks = 1;
     cls_pack_hidden_kernel<<<kF * kF / 256, 256, 0, stream>>>(d->W[1], s->wpk);
     cls_pack_hidden_kernel<<<kF * kF / 256, 256, 0, stream>>>(d->W[2], s->wpk + kF * kF);
@@ -666,6 +667,7 @@ int clscoop_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     p.state_slot = r.state_slot; p.N = r.N; p.seed = r.seed; p.elem_offset = r.elem_offset;
     p.T = r.T; p.t_hi = r.t_hi; p.t_lo = r.t_lo; p.C = s->y_dim; p.nq1 = s->nqs; p.guidance = s->cat_y_pred;
     p.out_mode = r.out_mode; p.eps_only = r.eps_only; p.n_z = r.n_z;
+    p.g_eff = 1;
     // hand-over buffer of the time slices: the sampler's own, or the library's static array (card_sampler_run_static)
     p.ybuf = s->ws;
     long long chunk_tiles = kChunkTiles;
@@ -674,37 +676,43 @@ int clscoop_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
         const long long fit = (long long)(r.workspace_bytes / ((size_t)kTileM * s->y_dim * sizeof(float)));
         chunk_tiles = fit < chunk_tiles ? fit : chunk_tiles;
     }
-    const char* ev = getenv("CARD_AMD_CLSCOOP_G");              // A/B: tile positions per workgroup (1 or 2)
-    const int G = (ev && ev[0] == '1') ? 1 : kGmax;
-    const char* sv = getenv("CARD_AMD_CLSCOOP_SLICE");          // A/B: 0 = no time slicing (rounds of whole loops)
-    const bool slicing = !(sv && sv[0] == '0');
-    const long long P = (long long)s->num_cu * G;               // slots one launch runs
+    const long long P = (long long)s->num_cu * kPerCu;          // slots one launch runs at a time: two one-tile workgroups per CU
     const int n_steps = r.t_hi - r.t_lo + 1;
-    // Two tile positions per CU: as TWO one-tile workgroups (PAIR form, the default: two waves per SIMD, the hardware
-    // interleaves them) or, CARD_AMD_CLSCOOP_FORM=two (A/B), as one workgroup that advances two tiles in its one instruction stream
-    const char* fv = getenv("CARD_AMD_CLSCOOP_FORM");
-    const bool pair = !(fv && fv[0] == 't') && G == 2;
+    const int C = s->y_dim;
     // compact LDS layout with the lin1 / lin4 fragments in LDS: up to 16 classes and tiles that span at most two input rows
-    // (CARD_AMD_CLSCOOP_FORM=pair1 keeps the plain PAIR layout, A/B)
-    const bool compact = pair && s->y_dim <= kCsmall && r.n_z >= kTileM && !(fv && strcmp(fv, "pair1") == 0);
-    auto launch = [&](int g_eff, long long grid) -> int {
-        if (pair && g_eff == 2) {
-            p.g_eff = 1;
-            // (at most the workgroups the chip holds at once, two per CU: the kernel walks the remaining slots in rounds)
-            const long long pn = p.q1 - p.q0 < 2LL * s->num_cu ? p.q1 - p.q0 : 2LL * s->num_cu;
-            const dim3 pgrid((unsigned)pn);
-            const bool multi = p.q1 - p.q0 > pn;
-            if (compact && multi) card_sample_cls_coop_kernel<1, 2, true><<<pgrid, dim3(kThreads), lds_floats(1, 2) * sizeof(float), stream>>>(p);
-            else if (compact) card_sample_cls_coop_kernel<1, 2><<<pgrid, dim3(kThreads), lds_floats(1, 2) * sizeof(float), stream>>>(p);
-            else if (multi) card_sample_cls_coop_kernel<1, 1, true><<<pgrid, dim3(kThreads), lds_floats(1) * sizeof(float), stream>>>(p);
-            else card_sample_cls_coop_kernel<1, 1><<<pgrid, dim3(kThreads), lds_floats(1) * sizeof(float), stream>>>(p);
-            HIP_TRY(hipGetLastError());
+    const bool compact = C <= kCsmall && r.n_z >= kTileM;
+    if (r.plan) {
+        // layer 1: the k-steps (q, e) with a real class 8q + e, two classes each; two F x F layers; lin4 as 16 (four-block
+        // MFMA) or 32 class columns; the hoisted y_0_hat part of layer 1 once per tile and call
+        int k1 = 0;
+        for (int q = 0; q < s->nqs; ++q)
+            for (int e = 0; e < 4; ++e) k1 += 8 * q + e < C ? 2 : 0;
+        r.plan->executed = 2.0 * kF * (k1 + 2 * kF + (C <= kCsmall ? kCsmall : kCmax)) + 2.0 * kF * 8 * s->nqs / (double)n_steps;
+    }
+    // slots [q0, q1): at most num_cu of them as one-tile workgroups with every fragment in registers (one per CU); more as
+    // the PAIR forms, two workgroups per CU, walking the slots beyond what the chip holds at once in rounds
+    auto launch = [&]() -> int {
+        const long long n = p.q1 - p.q0;
+        if (n <= s->num_cu) {
+            CARD_LAUNCH(r, "card_sample_cls_coop_kernel<ONE>", true,
+                        card_sample_cls_coop_kernel<0><<<dim3((unsigned)n), dim3(kThreads), lds_floats(0) * sizeof(float), stream>>>(p));
             return CARD_OK;
         }
-        p.g_eff = g_eff;
-        if (g_eff == 1) card_sample_cls_coop_kernel<1><<<dim3((unsigned)grid), dim3(kThreads), lds_floats(1) * sizeof(float), stream>>>(p);
-        else card_sample_cls_coop_kernel<2><<<dim3((unsigned)grid), dim3(kThreads), lds_floats(2) * sizeof(float), stream>>>(p);
-        HIP_TRY(hipGetLastError());
+        const long long pn = n < P ? n : P;
+        const dim3 pgrid((unsigned)pn);
+        const bool multi = n > pn;
+        if (compact && multi)
+            CARD_LAUNCH(r, "card_sample_cls_coop_kernel<PAIR compact, rounds>", true,
+                        card_sample_cls_coop_kernel<2, true><<<pgrid, dim3(kThreads), lds_floats(2) * sizeof(float), stream>>>(p));
+        else if (compact)
+            CARD_LAUNCH(r, "card_sample_cls_coop_kernel<PAIR compact>", true,
+                        card_sample_cls_coop_kernel<2><<<pgrid, dim3(kThreads), lds_floats(2) * sizeof(float), stream>>>(p));
+        else if (multi)
+            CARD_LAUNCH(r, "card_sample_cls_coop_kernel<PAIR, rounds>", true,
+                        card_sample_cls_coop_kernel<1, true><<<pgrid, dim3(kThreads), lds_floats(1) * sizeof(float), stream>>>(p));
+        else
+            CARD_LAUNCH(r, "card_sample_cls_coop_kernel<PAIR>", true,
+                        card_sample_cls_coop_kernel<1><<<pgrid, dim3(kThreads), lds_floats(1) * sizeof(float), stream>>>(p));
         return CARD_OK;
     };
     const long long tiles_total = (r.N + kTileM - 1) / kTileM;
@@ -712,15 +720,10 @@ int clscoop_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
         const long long nt = tiles_total - t0 < chunk_tiles ? tiles_total - t0 : chunk_tiles;
         p.n_begin = t0 * kTileM;
         p.n_end = (t0 + nt) * kTileM < r.N ? (t0 + nt) * kTileM : r.N;
-        if (nt <= s->num_cu) {                                   // one tile per workgroup, one launch
-            p.n_seg = 1; p.q0 = 0; p.q1 = nt;
-            if (int rc = launch(1, nt)) return rc;
-            continue;
-        }
         // segments: as many as make the last, partly filled slice cheap, at >= 32 timesteps each; one segment (whole
-        // loops, workgroups walking ceil(nt / P) rounds... here: slices of whole loops) when slicing is off or useless
+        // loops in one launch) when slicing is off (CARD_AMD_CLSCOOP=noslice) or useless
         int n_seg = 1;
-        if (slicing && !r.eps_only && nt > P && n_steps >= 64 && chunk_tiles >= P) {
+        if (!s->tune.cls_noslice && !r.eps_only && nt > P && n_steps >= 64 && chunk_tiles >= P) {
             double best = 1e300;
             for (int ns = 1; ns <= 16 && n_steps / ns >= 32; ++ns) {
                 const long long slices = (nt * ns + P - 1) / P;
@@ -730,16 +733,14 @@ int clscoop_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
         }
         p.n_seg = n_seg;
         const long long slots = nt * n_seg;
-        // a slice must not hold two segments of one tile: slices of at most nt slots (P <= nt whenever n_seg > 1)
-        // (un-sliced: ONE launch of all tile pairs -- the dispatcher walks them num_cu workgroups at a time; short calls
-        // such as the reference's per-timestep p_sample are launch- and prologue-bound, so fewer launches win)
+        // a slice must not hold two segments of one tile: slices of at most nt slots (P <= nt whenever n_seg > 1).
+        // Un-sliced: ONE launch whose workgroups walk all tiles (short calls such as the reference's per-timestep p_sample
+        // are launch- and prologue-bound, so fewer launches win).
         const long long per = n_seg > 1 ? P : slots;
         for (long long q0 = 0; q0 < slots; q0 += per) {
             p.q0 = q0;
             p.q1 = q0 + per < slots ? q0 + per : slots;
-            const long long n = p.q1 - p.q0;
-            const int g_eff = n > s->num_cu ? G : 1;
-            if (int rc = launch(g_eff, (n + g_eff - 1) / g_eff)) return rc;
+            if (int rc = launch()) return rc;
         }
     }
     return CARD_OK;

@@ -11,9 +11,9 @@
 //     lane yields the A operands of four consecutive MFMAs, conflict-free); per-step gamma rows are staged
 //     through a small wave-private LDS slab, prefetched one step ahead
 //   * layer 1: the step-invariant part b1 + W1[:,1:].(y_0_hat, x) is computed once per tile and one K=2 MFMA per
-//     output tile adds W1[:,0]*y_t each step (HOIST, any d_in): kept as two columns in LDS when rows are tiled
-//     in-kernel with n_z >= 32, else in a per-wave 16 KB scratch slot re-read from L2; or, un-hoisted, W1 stays in
-//     LDS and layer 1 runs on MFMA every step (d_in <= 32, CARD_AMD_HOIST=0)
+//     output tile adds W1[:,0]*y_t each step (any d_in): kept as two columns in LDS when rows are tiled in-kernel
+//     with n_z >= 32 (HOIST = 2), else in a per-wave 16 KB scratch slot re-read from L2 (HOIST = 1).  (Round 1's
+//     un-hoisted form -- W1 in LDS, layer 1 on MFMA every step, d_in <= 32 -- lost its A/B by 1.5-3.5 % and is gone.)
 //   * epilogue per element: xs = acc * (gamma*log2e); softplus/ln2 = xs > 20*log2e ? xs : log2(1 + exp2(xs))
 //     (ln2 is folded into the next layer's weights), i.e. F.softplus(beta=1, threshold=20)
 //   * measured on gfx950: v_mfma_f32_32x32x2_f32 barely overlaps with VALU work of either wave of a SIMD
@@ -38,9 +38,9 @@ constexpr int kOffW3 = kH * kH;           // 128x128 in fragment order
 constexpr int kOffB = 2 * kH * kH;        // b1 | b2 | b3
 constexpr int kOffW4 = kOffB + 3 * kH;    // W4 * ln2
 constexpr int kOffB4 = kOffW4 + kH;       // b4 (+3 pad)
-constexpr int kOffW1 = kOffB4 + 4;        // 128 x K1 in fragment order; HOIST kernels: column 0 of W1 (k1 = 1)
+constexpr int kOffW1 = kOffB4 + 4;        // column 0 of W1 (the y_t column)
 constexpr int kSlotFloats = kTileM * kH;  // one wave's hoisted layer-1 tile (32 chains x 128 features)
-__host__ __device__ constexpr int img_floats(int k1) { return kOffW1 + kH * k1; }
+constexpr int kImgFloats = kOffW1 + kH;
 constexpr int kGammaRow = 3 * kH;         // one timestep's gamma*log2e for the 3 layers
 
 }  // namespace
@@ -178,39 +178,19 @@ __device__ __forceinline__ void layer_first_hoisted(const float* slot, const flo
     }
 }
 
-template <int K1>
-__device__ __forceinline__ void layer_first(const float* wl, const float* bl, const float* gl, const float (&h0)[K1 / 2],
-                                            f32x16 (&hout)[4]) {
-    constexpr int NQ = K1 / 8;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        f32x16 acc;
-        load_bias(acc, bl, j);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const f32x4 a = lds4(wl + ((j * NQ + q) * 64) * 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], h0[4 * q + e], acc, 0, 0, 0);
-        }
-        epilogue_tile(acc, gl, j);
-        hout[j] = acc;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // The persistent sampler kernel (CARD_VARIANT_GUIDED, y_dim = 1, H = 128).
-//   HOIST = 0    : layer 1 runs on MFMA every step with W1 (K padded to K1 <= 32) resident in LDS.
 //   HOIST = 1    : any d_in; the step-invariant part of layer 1 is computed once per tile into the wave's
 //                  scratch slot (16 KB, re-read from L2 every step) and only W1[:,0]*y_t is added per step.
 // ------------------------------------------------------------------------------------------------
 //   HOIST = 2    : as 1, for in-kernel row tiling with n_z >= 32: the 32 chains of a tile then come from at most
 //                  two test rows, so the hoisted tile has only two distinct columns and lives in 1 KB of LDS per
 //                  wave -- no scratch slots, no per-step global traffic at all.
-template <int K1, int HOIST>
+template <int HOIST>
 __global__ __launch_bounds__(kThreads, 2) void card_sample_guided_kernel(const RunParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int IMG = img_floats(HOIST ? 1 : K1);
+    static_assert(HOIST == 1 || HOIST == 2, "layer 1 is always hoisted");
+    constexpr int IMG = kImgFloats;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -220,21 +200,18 @@ __global__ __launch_bounds__(kThreads, 2) void card_sample_guided_kernel(const R
 
     const int m = lane & 31, hh = lane >> 5;
     float* gst = lds + IMG + wave * kGammaRow;           // wave-private gamma slab
-    const float* w1l = lds + kOffW1 + lane * 4;
     const float* w2l = lds + kOffW2 + lane * 4;
     const float* w3l = lds + kOffW3 + lane * 4;
     const float* bl = lds + kOffB + 4 * hh;
     const float* w4l = lds + kOffW4 + 4 * hh;
     const float* gl = gst + 4 * hh;
     const float b4 = lds[kOffB4];
-    float a10[4] = {0.f, 0.f, 0.f, 0.f};
+    float a10[4];
     float* slot = nullptr;
     float* crow = lds + IMG + kWaves * kGammaRow + wave * (2 * kH) + 4 * hh;   // HOIST == 2: two hoisted columns
-    if constexpr (HOIST != 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a10[j] = hh == 0 ? lds[kOffW1 + 32 * j + m] : 0.0f;
-        if constexpr (HOIST == 1) slot = p.ws + ((long long)blockIdx.x * kWaves + wave) * kSlotFloats + lane * 4;
-    }
+    for (int j = 0; j < 4; ++j) a10[j] = hh == 0 ? lds[kOffW1 + 32 * j + m] : 0.0f;
+    if constexpr (HOIST == 1) slot = p.ws + ((long long)blockIdx.x * kWaves + wave) * kSlotFloats + lane * 4;
 
     const long long n_rows = p.n_end - p.n_begin;
     const long long n_tiles = (n_rows + kTileM - 1) / kTileM;
@@ -260,17 +237,8 @@ __global__ __launch_bounds__(kThreads, 2) void card_sample_guided_kernel(const R
             const int xi = k - 1 - (p.cat_y_pred ? 1 : 0);
             return (p.cat_x && xi < p.x_dim) ? p.x[rr * p.x_dim + xi] : 0.0f;
         };
-        // layer-1 input in B-operand order: k-step r takes feature 2r (lanes 0-31) and 2r+1 (lanes 32-63);
-        // feature 0 (y_t) is rewritten every step.
-        float h0[K1 / 2];
         int sel = 0;                       // HOIST == 2: which of the tile's two test rows this chain belongs to
-        if constexpr (HOIST == 0) {
-#pragma unroll
-            for (int r = 0; r < K1 / 2; ++r) {
-                const int k = 2 * r + hh;
-                h0[r] = k >= 1 ? static_feature(k) : 0.0f;
-            }
-        } else {
+        {
             // c1 = b1 + W1[:, 1:] . static features, once per tile, on MFMA with A fragments from global (L2)
             f32x16 c[4];
 #pragma unroll
@@ -317,8 +285,6 @@ __global__ __launch_bounds__(kThreads, 2) void card_sample_guided_kernel(const R
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        const float s0 = HOIST != 0 ? 0.0f : h0[0];
-
         float zc[4];
         uint32_t zblock = 0xFFFFFFFFu;
         auto draw = [&](int d) -> float {
@@ -366,13 +332,10 @@ __global__ __launch_bounds__(kThreads, 2) void card_sample_guided_kernel(const R
                 const float* sp = slot;
                 asm volatile("" : "+v"(sp));      // keep the slot reads inside the step loop (no LICM into 64 VGPRs)
                 layer_first_hoisted<256>(sp, a10, hh == 0 ? y : 0.0f, gl, hA);
-            } else if constexpr (HOIST == 2) {
+            } else {
                 const float* sp = crow + sel * kH;
                 asm volatile("" : "+v"(sp));
                 layer_first_hoisted<8>(sp, a10, hh == 0 ? y : 0.0f, gl, hA);
-            } else {
-                h0[0] = hh == 0 ? y : s0;
-                layer_first<K1>(w1l, bl, gl, h0, hA);
             }
             layer_hidden(w2l, bl + kH, gl + kH, hA, hB);
             layer_hidden(w3l, bl + 2 * kH, gl + 2 * kH, hB, hA);
@@ -1128,17 +1091,7 @@ __global__ void pack_hidden_kernel(const float* __restrict__ W, float scale, flo
     out[idx] = W[n * kH + k] * scale;
 }
 
-// layer 1: k-step r = 4q+e takes input feature 2r + (l>>5); columns >= d_in are zero padding
-__global__ void pack_first_kernel(const float* __restrict__ W1, int d_in, int K1, float* __restrict__ out) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= kH * K1) return;
-    const int nq = K1 / 8;
-    const int e = idx & 3, l = (idx >> 2) & 63, rest = idx >> 8, q = rest % nq, j = rest / nq;
-    const int n = 32 * j + (l & 31), k = 8 * q + 2 * e + (l >> 5);
-    out[idx] = k < d_in ? W1[n * d_in + k] : 0.0f;
-}
-
-// HOIST kernels: static columns 1..d_in-1 of W1; k-step 4q+e of group q takes feature 1 + 8q + 2e + (l>>5)
+// static columns 1..d_in-1 of W1; k-step 4q+e of group q takes feature 1 + 8q + 2e + (l>>5)
 __global__ void pack_static_kernel(const float* __restrict__ W1, int d_in, int nqs, float* __restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= kH * 8 * nqs) return;
@@ -1191,52 +1144,28 @@ __global__ void pack_gamma_kernel(const float* g1, const float* g2, const float*
 }
 
 
-typedef void (*sample_kernel_t)(const RunParams);
-
-sample_kernel_t guided_kernel_for(int k1, int hoist) {
-    if (hoist == 1) return card_sample_guided_kernel<8, 1>;
-    if (hoist == 2) return card_sample_guided_kernel<8, 2>;
-    switch (k1) {
-        case 8: return card_sample_guided_kernel<8, 0>;
-        case 16: return card_sample_guided_kernel<16, 0>;
-        case 24: return card_sample_guided_kernel<24, 0>;
-        case 32: return card_sample_guided_kernel<32, 0>;
-        default: return nullptr;
-    }
-}
-
 }  // namespace
 
 int guided_create(card_sampler* s, const card_model_desc* d, hipStream_t stream) {
     if (d->hidden != kH) return card_fail(CARD_E_UNSUPPORTED, "card_sampler_create: GUIDED hidden=%d, only 128 is built", d->hidden);
     if (d->y_dim != 1) return card_fail(CARD_E_UNSUPPORTED, "card_sampler_create: GUIDED y_dim=%d, only 1 is built", d->y_dim);
     const int d_in = s->d_in;
-    // Layer 1: hoisted (any d_in; default, 1.5-3.5 % faster at d_in 3-15 and the only form for d_in > 32) or
-    // LDS-resident MFMA every step (d_in <= 32, no scratch slots; CARD_AMD_HOIST=0 selects it for A/B runs).
-    bool hoist = true;
-    if (const char* ev = getenv("CARD_AMD_HOIST")) hoist = d_in > 32 || ev[0] != '0';
-    const int k1 = hoist ? 1 : (d_in + 7) / 8 * 8;
     const int nqs = (d_in - 1 + 7) / 8;
-    sample_kernel_t kern = guided_kernel_for(k1, hoist ? 1 : 0);
-    if (!kern) return card_fail(CARD_E_UNSUPPORTED, "card_sampler_create: no kernel for d_in=%d", d_in);
-    s->k1 = k1; s->kernel = reinterpret_cast<void*>(kern); s->hoist = hoist ? 1 : 0; s->nqs = nqs;
-    const int img = img_floats(k1);
-    s->lds_bytes = (size_t)(img + kWaves * kGammaRow + (hoist ? kWaves * 2 * kH : 0)) * sizeof(float);
-    HIP_TRY(hipMalloc(&s->wpk, (size_t)img * sizeof(float)));
+    s->nqs = nqs;
+    s->lds_bytes = (size_t)(kImgFloats + kWaves * kGammaRow + kWaves * 2 * kH) * sizeof(float);
+    HIP_TRY(hipMalloc(&s->wpk, (size_t)kImgFloats * sizeof(float)));
     HIP_TRY(hipMalloc(&s->gtab, (size_t)d->n_embed * kGammaRow * sizeof(float)));
-    if (hoist && nqs > 0) HIP_TRY(hipMalloc(&s->w1s, (size_t)kH * 8 * nqs * sizeof(float)));
-    if (hoist) HIP_TRY(hipMalloc(&s->ws, (size_t)s->num_cu * kWaves * kSlotFloats * sizeof(float)));
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
-    if (hoist) HIP_TRY(hipFuncSetAttribute((const void*)guided_kernel_for(k1, 2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
-    // cooperative small-batch form (needs the hoisted image layout); CARD_AMD_COOP=0 switches it off for A/B runs
+    if (nqs > 0) HIP_TRY(hipMalloc(&s->w1s, (size_t)kH * 8 * nqs * sizeof(float)));
+    HIP_TRY(hipMalloc(&s->ws, (size_t)s->num_cu * kWaves * kSlotFloats * sizeof(float)));
+    HIP_TRY(hipFuncSetAttribute((const void*)card_sample_guided_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
+    HIP_TRY(hipFuncSetAttribute((const void*)card_sample_guided_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
+    // cooperative small-batch forms (CARD_AMD_COOP=off keeps every batch size on the persistent kernel: tests, A/B)
     s->coop_blocks = 0;
-    const char* cv = getenv("CARD_AMD_COOP");
-    if (hoist && !(cv && cv[0] == '0')) {
+    if (!s->tune.coop_off) {
         int nb = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)card_sample_coop_kernel, kCoopThreads,
                                                              (size_t)kCoopLdsFloats * sizeof(float)));
         s->coop_blocks = nb < 1 ? 1 : (nb > 2 ? 2 : nb);
-        s->coop_force = (cv && cv[0] == '2') ? 1 : 0;     // CARD_AMD_COOP=2: cooperative kernel for every batch size (A/B)
         HIP_TRY(hipFuncSetAttribute((const void*)card_sample_coop2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(kCoop2LdsFloats * sizeof(float))));
         HIP_TRY(hipFuncSetAttribute((const void*)card_sample_coop16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1249,14 +1178,9 @@ int guided_create(card_sampler* s, const card_model_desc* d, hipStream_t stream)
     }
     pack_hidden_kernel<<<kH * kH / 256, 256, 0, stream>>>(d->W[1], kLn2, s->wpk + kOffW2);
     pack_hidden_kernel<<<kH * kH / 256, 256, 0, stream>>>(d->W[2], kLn2, s->wpk + kOffW3);
-    if (hoist)
-        if (int rc = split_create(s, d, stream)) return rc;      // CARD_ARITH_SPLIT_BF16 (reads the hoisted image's small tables)
-    if (hoist) {
-        pack_col0_kernel<<<1, kH, 0, stream>>>(d->W[0], d_in, s->wpk + kOffW1);
-        if (nqs > 0) pack_static_kernel<<<(kH * 8 * nqs + 255) / 256, 256, 0, stream>>>(d->W[0], d_in, nqs, s->w1s);
-    } else {
-        pack_first_kernel<<<(kH * k1 + 255) / 256, 256, 0, stream>>>(d->W[0], d_in, k1, s->wpk + kOffW1);
-    }
+    if (int rc = split_create(s, d, stream)) return rc;      // CARD_ARITH_SPLIT_BF16 (reads this image's small tables)
+    pack_col0_kernel<<<1, kH, 0, stream>>>(d->W[0], d_in, s->wpk + kOffW1);
+    if (nqs > 0) pack_static_kernel<<<(kH * 8 * nqs + 255) / 256, 256, 0, stream>>>(d->W[0], d_in, nqs, s->w1s);
     pack_misc_kernel<<<1, kH, 0, stream>>>(d->b[0], d->b[1], d->b[2], d->W4, d->b4, s->wpk);
     const int ng = d->n_embed * kGammaRow;
     pack_gamma_kernel<<<(ng + 255) / 256, 256, 0, stream>>>(d->gamma[0], d->gamma[1], d->gamma[2], d->n_embed, s->gtab);
@@ -1274,14 +1198,19 @@ void guided_destroy(card_sampler* s) {
     split_destroy(s);
 }
 
+// Cost ratios behind the small-batch dispatch.  Each is a ratio of CYCLE counts of kernels whose timestep touches no
+// memory beyond LDS / registers (weights in registers or LDS, gamma rows prefetched a step ahead), so it does not move
+// with the shader clock or with HBM speed; it would move with the MFMA issue rate of another chip generation.
+// Measured on MI355X, tools/bench_small.py (profiles/r03_small_batch_ab.jsonl):
+constexpr double kRho16 = 1.65;    // 16-chain tiles: timestep of two tiles sharing a CU (5.3 us) / of one tile alone (3.2 us)
+constexpr double kRho32 = 1.717;   // 32-chain tiles: 9.1 us / 5.3 us
+constexpr int kCoopMaxRoundsX2 = 7;  // cooperative form up to 3.5 rounds of 2 tiles per CU (9.0 ms per round against 18.0 / 33.8 ms
+                                     // per 4 / 8 tiles per CU on the persistent kernel)
+
 int guided_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     int arith = r.arith;
-    if (arith == CARD_ARITH_F32_MFMA)
-        if (const char* av = getenv("CARD_AMD_ARITH")) arith = av[0] == 's' ? CARD_ARITH_SPLIT_BF16 : arith;
-    if (arith == CARD_ARITH_SPLIT_BF16) {
-        if (!s->wsplit) return card_fail(CARD_E_UNSUPPORTED, "card_sampler_run: CARD_ARITH_SPLIT_BF16 needs the hoisted layer-1 image (CARD_AMD_HOIST=0 is set)");
-        return split_run(s, r, stream);
-    }
+    if (arith == CARD_ARITH_F32_MFMA && s->tune.arith_split) arith = CARD_ARITH_SPLIT_BF16;
+    if (arith == CARD_ARITH_SPLIT_BF16) return split_run(s, r, stream);
     RunParams p;
     memset(&p, 0, sizeof(p));
     p.wpk = s->wpk; p.gtab = s->gtab; p.coef = r.coef; p.x = r.x; p.y0hat = r.y0hat; p.ytmean = r.ytmean;
@@ -1292,42 +1221,37 @@ int guided_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     p.out_mode = r.out_mode; p.eps_only = r.eps_only; p.n_z = r.n_z;
     p.w1s = s->w1s; p.ws = s->ws; p.nqs = s->nqs;
     p.wpk16 = s->wpk16; p.w1s16 = s->w1s16;
+    // card_sampler_run_static: scratch comes from the library's static array; `scratch_bytes` bounds what a form may use
+    // of it (the sampler's own allocation holds the wave slots, which are larger than any hand-over buffer)
+    unsigned long long scratch_bytes = (unsigned long long)s->num_cu * kWaves * kSlotFloats * sizeof(float);
     if (r.lib_scratch) {
-        // card_sampler_run_static: the per-wave slots of the scratch-slot kernel come from the library's static array
-        const unsigned long long need = (unsigned long long)s->num_cu * kWaves * kSlotFloats * sizeof(float);
-        if (s->hoist && need > r.workspace_bytes)
-            return card_fail(CARD_E_UNSUPPORTED, "card_sampler_run_static: %d CUs need %llu bytes of wave slots, the static scratch has %llu",
-                             s->num_cu, need, r.workspace_bytes);
         p.ws = static_cast<float*>(r.workspace);
+        scratch_bytes = r.workspace_bytes;
     }
-    // Split very large N into launches of whole waves-worth of tiles so that one launch stays well under
-    // a second and every wave gets the same number of tiles (no intra-launch tail except in the last one).
+    const int n_steps = p.t_hi - p.t_lo + 1;
+    if (r.plan)      // layers 2-3, the K = 2 update of layer 1, lin4 (VALU), and the hoisted part once per tile and call
+        r.plan->executed = 2.0 * kH * (2 * kH) + 2.0 * kH * 2 + 2.0 * kH + 2.0 * kH * 8 * s->nqs / (double)n_steps;
     // Small batches (the reference's per-minibatch calls).  Measured per 1000 timesteps (tools/bench_small.py): the
-    // cooperative form takes 5.4 ms for up to num_cu tiles and 9.1 ms per round of 2 x num_cu tiles (two workgroups per
-    // CU); the persistent kernel 18.1 ms while every tile has a SIMD to itself (<= 4 x num_cu tiles), 33.8 ms up to
+    // cooperative form takes 5.3 ms for up to num_cu tiles and 9.0 ms per round of 2 x num_cu tiles (two workgroups per
+    // CU); the persistent kernel 18.0 ms while every tile has a SIMD to itself (<= 4 x num_cu tiles), 33.8 ms up to
     // 8 x num_cu tiles.  The cooperative form is ahead up to 3.5 rounds = 7 x num_cu tiles (57 344 chains on 256 CUs).
     const long long tiles_total = (p.N + kTileM - 1) / kTileM;
-    if (s->coop_blocks > 0 && (s->coop_force || tiles_total <= 7LL * s->num_cu)) {
+    if (s->coop_blocks > 0 && (s->tune.coop_force || tiles_total <= (long long)kCoopMaxRoundsX2 * s->num_cu)) {
         p.n_begin = 0;
         p.n_end = p.N;
+        const bool ybuf_fits = (unsigned long long)p.N * sizeof(float) <= scratch_bytes;   // chain states between time slices
         // Up to two 16-chain tiles per CU (8 192 chains on 256 CUs; BASELINE configs[0] is 5 100): the 16-chain-tile kernel,
         // one tile per CU up to num_cu tiles, the time-sliced single / paired scheme between num_cu and 2 x num_cu.
-        // CARD_AMD_COOP16=0: off (A/B; results are bit-identical either way).
-        const char* c16 = getenv("CARD_AMD_COOP16");
-        const long long tiles16 = (p.N + kT16 - 1) / kT16;
-        // (a CU sharing two 16-chain tiles takes 5.46 us per timestep, one 32-chain tile alone 5.3 us: above 15/8 tiles
+        // (a CU sharing two 16-chain tiles takes 5.3 us per timestep, one 32-chain tile alone 5.3 us: above 15/8 tiles
         // per CU the 32-chain form below is as fast)
-        if (s->coop_blocks == 2 && !(c16 && c16[0] == '0') && s->wpk16 && tiles16 <= 2LL * s->num_cu - s->num_cu / 8 && p.ws) {
-            const int n_steps16 = p.t_hi - p.t_lo + 1;
+        const long long tiles16 = (p.N + kT16 - 1) / kT16;
+        if (s->coop_blocks == 2 && !s->tune.coop_no16 && s->wpk16 && tiles16 <= 2LL * s->num_cu - s->num_cu / 8) {
             long long n_single = tiles16 <= s->num_cu ? tiles16 : 2LL * s->num_cu - tiles16;
-            int K = 1, S = n_steps16, L = n_steps16;
-            const bool fits16 = !r.lib_scratch || (unsigned long long)p.N * sizeof(float) <= r.workspace_bytes;
-            if (tiles16 > s->num_cu && n_single > 0 && !p.eps_only && n_steps16 >= 64 && fits16) {
-                double rho = 1.65;                                 // paired (5.46 us) / single (3.3 us) cost of a timestep, measured
-                if (const char* rv = getenv("CARD_AMD_COOP16_RHO")) rho = atof(rv) > 1.0 ? atof(rv) : rho;
+            int K = 1, S = n_steps, L = n_steps;
+            if (tiles16 > s->num_cu && n_single > 0 && !p.eps_only && n_steps >= 64 && ybuf_fits) {
                 const int K2 = (int)((tiles16 + n_single - 1) / n_single);
-                const int S2 = (int)((double)n_steps16 / ((double)(K2 - 1) + rho) + 0.5);
-                const int L2 = n_steps16 - (K2 - 1) * S2;
+                const int S2 = (int)((double)n_steps / ((double)(K2 - 1) + kRho16) + 0.5);
+                const int L2 = n_steps - (K2 - 1) * S2;
                 if (K2 <= 8 && S2 >= 8 && L2 >= S2) { K = K2; S = S2; L = L2; }
             }
             if (K == 1 && tiles16 > s->num_cu) n_single = 2LL * s->num_cu - tiles16 > 0 ? 2LL * s->num_cu - tiles16 : 0;
@@ -1338,28 +1262,21 @@ int guided_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
                 n_s = n_s > n_single ? n_single : (n_s < 0 ? 0 : n_s);
                 const long long grid = n_s + (tiles16 - n_s + 1) / 2;
                 p.sl_k = k;
-                card_sample_coop16_kernel<<<dim3((unsigned)grid), dim3(kCoop2Threads), (size_t)kCoop16LdsFloats * sizeof(float), stream>>>(p);
-                HIP_TRY(hipGetLastError());
+                CARD_LAUNCH(r, "card_sample_coop16_kernel", true,
+                            card_sample_coop16_kernel<<<dim3((unsigned)grid), dim3(kCoop2Threads), (size_t)kCoop16LdsFloats * sizeof(float), stream>>>(p));
             }
             return CARD_OK;
         }
         // Between one and two tiles per CU (the reference's Year minibatch: 12 800 chains = 400 tiles): the time-sliced
         // paired form, see card_sample_coop2_kernel.  n_single CUs' worth of tiles run alone in each slice; every tile
-        // does so in exactly one of the K slices.  rho = the measured cost ratio of a timestep on a shared CU (9.1 us
-        // for its two tiles) to one on a CU of its own (5.3 us): tools/bench_small.py.  CARD_AMD_COOP2=0: off (A/B).
-        const char* c2 = getenv("CARD_AMD_COOP2");
-        const int n_steps = p.t_hi - p.t_lo + 1;
-        if (s->coop_blocks == 2 && !(c2 && c2[0] == '0') && !p.eps_only && tiles_total > s->num_cu &&
-            tiles_total < 2LL * s->num_cu && n_steps >= 64 && p.ws) {
-            double rho = 1.717;
-            if (const char* rv = getenv("CARD_AMD_COOP2_RHO")) rho = atof(rv) > 1.0 ? atof(rv) : rho;     // tuning runs
+        // does so in exactly one of the K slices.
+        if (s->coop_blocks == 2 && !s->tune.coop_no2 && !p.eps_only && tiles_total > s->num_cu &&
+            tiles_total < 2LL * s->num_cu && n_steps >= 64 && ybuf_fits) {
             const long long n_single = 2LL * s->num_cu - tiles_total;
             const int K = (int)((tiles_total + n_single - 1) / n_single);
-            const int S = (int)((double)n_steps / ((double)(K - 1) + rho) + 0.5);
+            const int S = (int)((double)n_steps / ((double)(K - 1) + kRho32) + 0.5);
             const int L = n_steps - (K - 1) * S;
-            const unsigned long long need = (unsigned long long)p.N * sizeof(float);
-            const bool fits = !r.lib_scratch || need <= r.workspace_bytes;       // (the sampler's own slots always do)
-            if (K <= 8 && S >= 8 && L >= S && fits) {
+            if (K <= 8 && S >= 8 && L >= S) {
                 p.ybuf = p.ws;
                 p.sl_K = K; p.sl_nsingle = (int)n_single; p.sl_S = S; p.sl_L = L;
                 for (int k = 0; k < K; ++k) {
@@ -1367,17 +1284,28 @@ int guided_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
                     n_s = n_s > n_single ? n_single : n_s;
                     const long long grid = n_s + (tiles_total - n_s + 1) / 2;
                     p.sl_k = k;
-                    card_sample_coop2_kernel<<<dim3((unsigned)grid), dim3(kCoop2Threads), (size_t)kCoop2LdsFloats * sizeof(float), stream>>>(p);
-                    HIP_TRY(hipGetLastError());
+                    CARD_LAUNCH(r, "card_sample_coop2_kernel", true,
+                                card_sample_coop2_kernel<<<dim3((unsigned)grid), dim3(kCoop2Threads), (size_t)kCoop2LdsFloats * sizeof(float), stream>>>(p));
                 }
                 return CARD_OK;
             }
         }
         const long long cap = (long long)s->num_cu * s->coop_blocks;
         const long long grid = tiles_total < cap ? tiles_total : cap;
-        card_sample_coop_kernel<<<dim3((unsigned)grid), dim3(kCoopThreads), (size_t)kCoopLdsFloats * sizeof(float), stream>>>(p);
-        HIP_TRY(hipGetLastError());
+        CARD_LAUNCH(r, "card_sample_coop_kernel", true,
+                    card_sample_coop_kernel<<<dim3((unsigned)grid), dim3(kCoopThreads), (size_t)kCoopLdsFloats * sizeof(float), stream>>>(p));
         return CARD_OK;
+    }
+    // Very large N: launches of whole waves-worth of tiles so that one launch stays well under a second and every wave
+    // gets the same number of tiles (no intra-launch tail except in the last one).
+    // in-kernel row tiling with n_z >= 32: the hoisted layer-1 tile has two distinct columns -> LDS-resident form (HOIST = 2)
+    const bool two_col = r.n_z >= 32;
+    if (!two_col && r.lib_scratch) {
+        // only this form needs the per-wave slots, 16 KB per resident wave
+        const unsigned long long need = (unsigned long long)s->num_cu * kWaves * kSlotFloats * sizeof(float);
+        if (need > r.workspace_bytes)
+            return card_fail(CARD_E_UNSUPPORTED, "card_sampler_run_static: %d CUs need %llu bytes of wave slots, the static scratch has %llu",
+                             s->num_cu, need, r.workspace_bytes);
     }
     const long long waves = (long long)s->num_cu * kWaves;
     const long long tiles_per_wave = 16;
@@ -1387,10 +1315,10 @@ int guided_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
         p.n_end = b + chunk < p.N ? b + chunk : p.N;
         const long long tiles = (p.n_end - p.n_begin + kTileM - 1) / kTileM;
         const long long grid = tiles < s->num_cu ? tiles : s->num_cu;
-        // in-kernel row tiling with n_z >= 32: the hoisted layer-1 tile has two distinct columns -> LDS-resident form
-        sample_kernel_t kern = (s->hoist && r.n_z >= 32) ? guided_kernel_for(s->k1, 2) : reinterpret_cast<sample_kernel_t>(s->kernel);
-        kern<<<dim3((unsigned)grid), dim3(kThreads), s->lds_bytes, stream>>>(p);
-        HIP_TRY(hipGetLastError());
+        if (two_col)
+            CARD_LAUNCH(r, "card_sample_guided_kernel<2>", true, card_sample_guided_kernel<2><<<dim3((unsigned)grid), dim3(kThreads), s->lds_bytes, stream>>>(p));
+        else
+            CARD_LAUNCH(r, "card_sample_guided_kernel<1>", true, card_sample_guided_kernel<1><<<dim3((unsigned)grid), dim3(kThreads), s->lds_bytes, stream>>>(p));
     }
     return CARD_OK;
 }

@@ -3,6 +3,48 @@
 #define CARD_INTERNAL_H
 #include "card_common.h"
 
+// What card_sampler_plan reports.  A plan is a DRY RUN of the back end's run function: the same code takes the same
+// decisions and, where it would launch, only notes the kernel (CARD_LAUNCH below), so a plan cannot drift from the dispatch.
+struct CardPlanRec {
+    int launches, dominant_launches;
+    char kernel[96];
+    double executed;        // matrix-pipe + lin4 flops the kernels issue per sample-step
+};
+inline bool card_plan_note(CardPlanRec* pl, const char* name, bool dominant) {
+    if (!pl) return false;
+    pl->launches++;
+    if (dominant) {
+        pl->dominant_launches++;
+        if (!pl->kernel[0]) snprintf(pl->kernel, sizeof(pl->kernel), "%s", name);
+    }
+    return true;
+}
+// CARD_LAUNCH(r, "kernel name", carries_the_flops, kernel<<<grid, block, lds, stream>>>(args));
+#define CARD_LAUNCH(r, name, dominant, ...)                      \
+    do {                                                         \
+        if (!card_plan_note((r).plan, name, dominant)) {         \
+            __VA_ARGS__;                                         \
+            HIP_TRY(hipGetLastError());                          \
+        }                                                        \
+    } while (0)
+
+// Form switches, for tests and A/B runs: ONE environment variable per back end, a comma-separated token list, read ONCE
+// when a sampler is created (card_tune_from_env, card_api.hip) and kept in the sampler; a run reads no environment.
+//   CARD_AMD_COOP     regression, hidden 128:  off (0) = persistent kernel for every batch size | force (2) = cooperative
+//                     kernel for every batch size | no16 = no 16-chain-tile form | no2 = no time-sliced paired form
+//   CARD_AMD_STREAM   regression, hidden 256:  off (0) = GEMM back end instead | big = no four-wave small-batch form
+//   CARD_AMD_CLSCOOP  classification, F = 128: off (0) = GEMM back end instead | noslice = no round-robin time slicing
+//   CARD_AMD_WIDE     GEMM back end:           gemmhead = lin4 as a GEMM launch also up to 32 classes | notail = no 64 x 64 tail tiles
+//   CARD_AMD_ARITH    split = CARD_ARITH_SPLIT_BF16 for calls that leave card_run_args.arith at 0
+struct CardTune {
+    int coop_off, coop_force, coop_no16, coop_no2;
+    int stream_off, stream_big;
+    int cls_off, cls_noslice;
+    int wide_gemmhead, wide_notail;
+    int arith_split;
+};
+void card_tune_from_env(CardTune* t);
+
 // Launch-level arguments shared by both back ends (validated by card_sampler_run / card_eps_theta).
 struct CardRun {
     const float* x;         // GUIDED: x (N, x_dim);  BN_HADAMARD: x_feat (N, F)
@@ -22,16 +64,18 @@ struct CardRun {
     int arith;              // card_arith
     int lib_scratch;        // card_sampler_run_static: `workspace` is the library's per-GPU static array, to be used
                             // for every scratch buffer of the back end (also in place of the sampler's own slots)
+    CardPlanRec* plan;      // not NULL: dry run for card_sampler_plan (no launch, no device access)
 };
 
 struct card_sampler {
     int variant, x_dim, y_dim, hidden, n_embed, cat_x, cat_y_pred;
     int d_in;
     int device, num_cu;
+    CardTune tune; // form switches read from the environment at create time
     int backend;   // 0: persistent kernel (card_guided.hip), 1: streaming GEMMs (card_wide.hip), 2: persistent kernel with streamed weights (card_stream.hip), 3: cooperative classification kernel (card_clscoop.hip)
     // ---- CARD_VARIANT_GUIDED (card_guided.hip)
-    int k1, hoist, nqs;
-    int coop_force;
+    int nqs;           // k-step groups of the hoisted static columns of W1 (card_clscoop.hip: of the class columns)
+    int k1;            // card_stream.hip: k-steps of layer 1
     int coop_blocks;   // > 0: workgroups per CU of the cooperative small-batch kernel (0: not available)
     float* wpk;    // packed LDS image
     float* gtab;   // (n_embed, 3, H) gamma * log2e [* bn_scale]
@@ -65,7 +109,7 @@ void wide_destroy(card_sampler* s);
 int wide_run(const card_sampler* s, const CardRun& r, hipStream_t stream);
 unsigned long long wide_workspace_bytes(const card_sampler* s, long long N);
 
-bool stream_supports(const card_model_desc* d, int d_in);
+bool stream_supports(const card_model_desc* d, int d_in, const CardTune& tune);
 int stream_create(card_sampler* s, const card_model_desc* d, hipStream_t stream);
 void stream_destroy(card_sampler* s);
 int stream_run(const card_sampler* s, const CardRun& r, hipStream_t stream);
@@ -75,7 +119,7 @@ int fphi_in_dim(const card_fphi* f);
 int fphi_out_dim(const card_fphi* f);
 int fphi_forward(const card_fphi* f, const float* x, long long rows, float* out, hipStream_t stream);
 
-bool clscoop_supports(const card_model_desc* d);
+bool clscoop_supports(const card_model_desc* d, const CardTune& tune);
 int clscoop_create(card_sampler* s, const card_model_desc* d, hipStream_t stream);
 void clscoop_destroy(card_sampler* s);
 int clscoop_run(const card_sampler* s, const CardRun& r, hipStream_t stream);

@@ -514,13 +514,14 @@ int split_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     // a workgroup rotates three tiles through the three stages of a timestep; a launch covers kGroupsPerWg such groups
     // per CU (launches stay under ~0.5 s), fewer workgroups than CUs only when the batch has fewer groups
     const long long chunk = (long long)s->num_cu * kGroupsPerWg * kSets * kTileM;
+    if (r.plan) r.plan->executed = 6.0 * 2 * kH * (2 * kH);      // bf16 flops: six partial products per k-step of the two hidden layers
     for (long long b = 0; b < r.N; b += chunk) {
         p.n_begin = b;
         p.n_end = b + chunk < r.N ? b + chunk : r.N;
         const long long groups = ((p.n_end - p.n_begin + kTileM - 1) / kTileM + kSets - 1) / kSets;
         const long long grid = groups < s->num_cu ? groups : s->num_cu;
-        card_sample_split_kernel<<<dim3((unsigned)grid), dim3(kThreads8), (size_t)kLdsBytes, stream>>>(p);
-        HIP_TRY(hipGetLastError());
+        CARD_LAUNCH(r, "card_sample_split_kernel", true,
+                    card_sample_split_kernel<<<dim3((unsigned)grid), dim3(kThreads8), (size_t)kLdsBytes, stream>>>(p));
     }
     return CARD_OK;
 }

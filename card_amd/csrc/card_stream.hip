@@ -371,9 +371,8 @@ stream_kernel_t stream_kernel_for(int H, int ks1, int waves) {
 
 }  // namespace
 
-bool stream_supports(const card_model_desc* d, int d_in) {
-    if (const char* ev = getenv("CARD_AMD_STREAM"))
-        if (ev[0] == '0') return false;                 // A/B: force the GEMM back end
+bool stream_supports(const card_model_desc* d, int d_in, const CardTune& tune) {
+    if (tune.stream_off) return false;                  // CARD_AMD_STREAM=off: the GEMM back end instead (tests, A/B)
     return d->variant == CARD_VARIANT_GUIDED && d->y_dim == 1 && d->hidden == 256 && stream_ks1_for(d_in) != 0;
 }
 
@@ -414,11 +413,12 @@ int stream_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     p.x_dim = s->x_dim; p.cat_x = s->cat_x; p.cat_y_pred = s->cat_y_pred;
     p.out_mode = r.out_mode; p.eps_only = r.eps_only; p.n_z = r.n_z;
     // Small batches (at most num_cu * 4 waves * 16 chains = 16 384 on 256 CUs): four waves per workgroup, one per SIMD,
-    // so every SIMD of the chip gets a tile; the 8-wave form would run them on half of the CUs.  CARD_AMD_STREAM_SMALL=0
+    // so every SIMD of the chip gets a tile; the 8-wave form would run them on half of the CUs.  CARD_AMD_STREAM=big
     // keeps the 8-wave form (A/B); results are identical (same per-chain arithmetic).
-    const bool small_ok = !(getenv("CARD_AMD_STREAM_SMALL") && getenv("CARD_AMD_STREAM_SMALL")[0] == '0');
-    const bool small = small_ok && p.N <= (long long)s->num_cu * kWavesSmall * kTile;
+    const bool small = !s->tune.stream_big && p.N <= (long long)s->num_cu * kWavesSmall * kTile;
     const int waves = small ? kWavesSmall : kWavesFull;
+    if (r.plan)      // layer 1 on MFMA every step with K padded to 4 * ks1 columns, two H x H layers, lin4 (VALU)
+        r.plan->executed = 2.0 * s->hidden * (4 * s->k1 + 2 * s->hidden) + 2.0 * s->hidden;
     stream_kernel_t kern = small ? stream_kernel_for(s->hidden, s->k1, kWavesSmall) : reinterpret_cast<stream_kernel_t>(s->kernel);
     // launches of at most num_cu workgroups x kGroupsPerWg groups x 128 chains: every workgroup walks the same
     // number of groups (the kernel's barriers need that) and one launch stays well under a second
@@ -429,8 +429,8 @@ int stream_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
         p.n_end = b + chunk < p.N ? b + chunk : p.N;
         const long long groups = (p.n_end - p.n_begin + group - 1) / group;
         const long long grid = groups < s->num_cu ? groups : s->num_cu;
-        kern<<<dim3((unsigned)grid), dim3(waves * 64), s->lds_bytes, stream>>>(p);
-        HIP_TRY(hipGetLastError());
+        CARD_LAUNCH(r, small ? "card_sample_stream_kernel (4 waves)" : "card_sample_stream_kernel", true,
+                    kern<<<dim3((unsigned)grid), dim3(waves * 64), s->lds_bytes, stream>>>(p));
     }
     return CARD_OK;
 }

@@ -31,15 +31,9 @@ constexpr int kStageFloats = (BM + BN) * LDT;
 // One LDS stage (36 KB: the next k tile waits in registers while this one is computed, two barriers per tile) and four
 // workgroups per CU beat round 1's two stages / two workgroups per CU: four waves per SIMD keep the matrix pipe fed through
 // each other's barriers (CIFAR-10 minibatch 12.24 -> 11.73 ms per timestep; three per CU 11.85).  128 VGPRs: the compiler
-// spills 14 registers, all of them in the epilogue.  -DCARD_WIDE_2STAGE / -DCARD_WIDE_WG3 build the other forms (A/B).
-#if defined(CARD_WIDE_2STAGE)
-constexpr int kGemmStages = 2, kGemmWgPerCu = 2;
-#elif defined(CARD_WIDE_WG3)
-constexpr int kGemmStages = 1, kGemmWgPerCu = 3;
-#else
-constexpr int kGemmStages = 1, kGemmWgPerCu = 4;
-#endif
-constexpr int kGemmLds = kGemmStages * kStageFloats * (int)sizeof(float);   // 36 864 B per stage
+// spills 14 registers, all of them in the epilogue.  (The two-stage and three-workgroup builds of round 2 are gone.)
+constexpr int kGemmWgPerCu = 4;
+constexpr int kGemmLds = kStageFloats * (int)sizeof(float);   // 36 864 B
 
 constexpr int kHeadFusedMaxC = 32;     // wide_head_update_kernel
 enum { EPI_SOFTPLUS = 0, EPI_BIAS = 1, EPI_SOFTPLUS_MUL = 2, EPI_SCALE = 3, EPI_SCALE_MUL = 4 };
@@ -128,7 +122,6 @@ __device__ __forceinline__ void wide_gemm_tile(const float* __restrict__ A, cons
     g_load(0);
     s_store(0);
     __syncthreads();
-#ifndef CARD_WIDE_2STAGE
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
         if (more) g_load(kt + 1);
@@ -137,24 +130,6 @@ __device__ __forceinline__ void wide_gemm_tile(const float* __restrict__ A, cons
         if (more) s_store(0);
         __syncthreads();
     }
-#else
-    int kt = 0;
-    for (; kt + 2 <= nk; kt += 2) {                        // two k tiles per trip: stage 0 then stage 1
-        const bool more = kt + 2 < nk;
-        g_load(kt + 1);
-        compute(0);
-        s_store(1);
-        __syncthreads();
-        if (more) g_load(kt + 2);
-        compute(1);
-        if (more) s_store(0);
-        __syncthreads();
-    }
-    if (kt < nk) {                                         // odd tile count (layer 1: K = 32): last tile sits in stage 0
-        compute(0);
-        __syncthreads();
-    }
-#endif
     // Hadamard operand row of each chain row of this block (chain / n_z), one 64-bit division per row instead of
     // one per element: table in LDS (the tiles are dead after the loop's last barrier)
     int* mrow = reinterpret_cast<int*>(sm);
@@ -532,12 +507,12 @@ WideWs carve(void* base, long long N, int F, int Kp, int Cpad) {
 
 // out[M x Nout] = epilogue(A[M x K] . W[Nout x K]^T).  Whole rounds of kGemmWgPerCu x num_cu resident 128 x 128 tiles, then, when the
 // last round would fill at most half of the chip, its rows as 64 x 64 tiles (see wide_gemm_tile) -- all in one launch.
-int gemm(int epi, const float* A, const float* W, const float* bias, const float* g, const float* sh, const float* mul,
-         int mul_div, float* out, long long M, int K, int Nout, int ldo, int num_cu, hipStream_t stream) {
+int gemm(const card_sampler* s, const CardRun& r, int epi, const float* A, const float* W, const float* bias, const float* g, const float* sh,
+         const float* mul, int mul_div, float* out, long long M, int K, int Nout, int ldo, hipStream_t stream) {
+    const int num_cu = s->num_cu;
     const long long cols = Nout / BN, rb = (M + BM - 1) / BM, slots = (long long)kGemmWgPerCu * num_cu;
     long long main_rb = rb;
-    const char* te = getenv("CARD_AMD_WIDE_TAIL");                  // A/B and tests: 0 = 128 x 128 tiles only
-    const bool tail_on = !(te && te[0] == '0');
+    const bool tail_on = !s->tune.wide_notail;                       // CARD_AMD_WIDE=notail: 128 x 128 tiles only (tests, A/B)
     if (tail_on && K >= 8 * BK && cols <= slots) {
         const long long rb_round = slots / cols;                       // row blocks of one round of resident workgroups
         const long long tail_rb = rb % rb_round;
@@ -547,17 +522,17 @@ int gemm(int epi, const float* A, const float* W, const float* bias, const float
     const long long n_main = main_rb * cols, n_tail = (M - m_main + 63) / 64 * (2 * cols);
     const dim3 grid((unsigned)(n_main + n_tail));
     const int c = (int)cols;
+    const bool big = K == Nout;                      // the F x F layers carry the flops
     if (epi == EPI_SOFTPLUS)
-        wide_gemm_kernel<EPI_SOFTPLUS><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo, c, n_main, m_main);
+        CARD_LAUNCH(r, "wide_gemm_kernel<EPI_SOFTPLUS>", big, wide_gemm_kernel<EPI_SOFTPLUS><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo, c, n_main, m_main));
     else if (epi == EPI_SOFTPLUS_MUL)
-        wide_gemm_kernel<EPI_SOFTPLUS_MUL><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo, c, n_main, m_main);
+        CARD_LAUNCH(r, "wide_gemm_kernel<EPI_SOFTPLUS_MUL>", false, wide_gemm_kernel<EPI_SOFTPLUS_MUL><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo, c, n_main, m_main));
     else if (epi == EPI_SCALE)
-        wide_gemm_kernel<EPI_SCALE><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo, c, n_main, m_main);
+        CARD_LAUNCH(r, "wide_gemm_kernel<EPI_SCALE>", big, wide_gemm_kernel<EPI_SCALE><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo, c, n_main, m_main));
     else if (epi == EPI_SCALE_MUL)
-        wide_gemm_kernel<EPI_SCALE_MUL><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo, c, n_main, m_main);
+        CARD_LAUNCH(r, "wide_gemm_kernel<EPI_SCALE_MUL>", false, wide_gemm_kernel<EPI_SCALE_MUL><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo, c, n_main, m_main));
     else
-        wide_gemm_kernel<EPI_BIAS><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo, c, n_main, m_main);
-    HIP_TRY(hipGetLastError());
+        CARD_LAUNCH(r, "wide_gemm_kernel<EPI_BIAS>", false, wide_gemm_kernel<EPI_BIAS><<<grid, 256, kGemmLds, stream>>>(A, W, bias, g, sh, mul, mul_div, out, M, K, ldo, c, n_main, m_main));
     return CARD_OK;
 }
 
@@ -653,21 +628,20 @@ int wide_run_chunk(const card_sampler* s, const CardRun& r, long long stride, hi
         int rc;
         if (s->variant == CARD_VARIANT_LINEAR_HADAMARD) {
             // lin3( gamma2 * lin2( linx(z) * (gamma1 * lin1(S)) ) ), imagenet/card/builder.py:86-92
-            if ((rc = gemm(EPI_SCALE_MUL, w.S, s->W1, b1, g, s->shift, r.x, r.n_z, w.hA, N, Kp, F, F, s->num_cu, stream))) return rc;
+            if ((rc = gemm(s, r, EPI_SCALE_MUL, w.S, s->W1, b1, g, s->shift, r.x, r.n_z, w.hA, N, Kp, F, F, stream))) return rc;
             *last = w.hB;
-            return gemm(EPI_SCALE, w.hA, s->W2, b2, g + F, s->shift + F, nullptr, 1, w.hB, N, F, F, F, s->num_cu, stream);
+            return gemm(s, r, EPI_SCALE, w.hA, s->W2, b2, g + F, s->shift + F, nullptr, 1, w.hB, N, F, F, F, stream);
         }
-        if ((rc = gemm(guided ? EPI_SOFTPLUS : EPI_SOFTPLUS_MUL, w.S, s->W1, b1, g, s->shift, r.x, r.n_z, w.hA, N, Kp, F, F, s->num_cu, stream))) return rc;
-        if ((rc = gemm(EPI_SOFTPLUS, w.hA, s->W2, b2, g + F, s->shift + F, nullptr, 1, w.hB, N, F, F, F, s->num_cu, stream))) return rc;
+        if ((rc = gemm(s, r, guided ? EPI_SOFTPLUS : EPI_SOFTPLUS_MUL, w.S, s->W1, b1, g, s->shift, r.x, r.n_z, w.hA, N, Kp, F, F, stream))) return rc;
+        if ((rc = gemm(s, r, EPI_SOFTPLUS, w.hA, s->W2, b2, g + F, s->shift + F, nullptr, 1, w.hB, N, F, F, F, stream))) return rc;
         *last = w.hA;
-        return gemm(EPI_SOFTPLUS, w.hB, s->W3, b3, g + 2 * (size_t)F, s->shift + 2 * (size_t)F, nullptr, 1, w.hA, N, F, F, F, s->num_cu, stream);
+        return gemm(s, r, EPI_SOFTPLUS, w.hB, s->W3, b3, g + 2 * (size_t)F, s->shift + 2 * (size_t)F, nullptr, 1, w.hA, N, F, F, F, stream);
     };
-    // lin4 as a GEMM launch into w.eps (N x Cpad): more than kHeadFusedMaxC classes, or CARD_AMD_WIDE_HEAD=gemm (A/B)
+    // lin4 as a GEMM launch into w.eps (N x Cpad): more than kHeadFusedMaxC classes, or CARD_AMD_WIDE=gemmhead (tests, A/B)
     auto head_gemm = [&](const float* last) -> int {
-        return gemm(EPI_BIAS, last, s->W4, b4, nullptr, nullptr, nullptr, 1, w.eps, N, F, Cpad, Cpad, s->num_cu, stream);
+        return gemm(s, r, EPI_BIAS, last, s->W4, b4, nullptr, nullptr, nullptr, 1, w.eps, N, F, Cpad, Cpad, stream);
     };
-    const char* hv = getenv("CARD_AMD_WIDE_HEAD");
-    const bool fused_head = C <= kHeadFusedMaxC && !(hv && hv[0] == 'g');
+    const bool fused_head = C <= kHeadFusedMaxC && !s->tune.wide_gemmhead;
     // lin4 + posterior update (or eps only) in one VALU launch
     auto head_fused = [&](const HeadParams& hp) -> int {
         // a wave owns RW = 64 / CP rows at a time; as many waves as give every wave the same number of row groups
@@ -675,10 +649,9 @@ int wide_run_chunk(const card_sampler* s, const CardRun& r, long long stride, hi
         const long long sgroups = ((N + RW - 1) / RW + 3) / 4, max_wgs = (long long)s->num_cu * 2;   // resident workgroups (registers)
         const long long rounds = (sgroups + max_wgs - 1) / max_wgs;
         const dim3 grid((unsigned)((sgroups + rounds - 1) / rounds));
-        if (C <= 8) wide_head_update_kernel<8, 8><<<grid, 256, 0, stream>>>(hp);
-        else if (C <= 16) wide_head_update_kernel<16, 4><<<grid, 256, 0, stream>>>(hp);
-        else wide_head_update_kernel<32, 2><<<grid, 256, 0, stream>>>(hp);
-        HIP_TRY(hipGetLastError());
+        if (C <= 8) CARD_LAUNCH(r, "wide_head_update_kernel<8>", false, wide_head_update_kernel<8, 8><<<grid, 256, 0, stream>>>(hp));
+        else if (C <= 16) CARD_LAUNCH(r, "wide_head_update_kernel<16>", false, wide_head_update_kernel<16, 4><<<grid, 256, 0, stream>>>(hp));
+        else CARD_LAUNCH(r, "wide_head_update_kernel<32>", false, wide_head_update_kernel<32, 2><<<grid, 256, 0, stream>>>(hp));
         return CARD_OK;
     };
     HeadParams hp;
@@ -686,9 +659,9 @@ int wide_run_chunk(const card_sampler* s, const CardRun& r, long long stride, hi
     hp.W4 = s->W4; hp.b4 = b4; hp.mu = r.ytmean; hp.S = w.S; hp.out = r.out; hp.N = N; hp.slot_stride = stride;
     hp.seed = r.seed; hp.elem_offset = r.elem_offset; hp.F = F; hp.C = C; hp.Kp = Kp; hp.n_z = r.n_z;
     // static columns of S (+ y_t when the caller supplies it)
-    wide_pack_state_kernel<<<grid_for(N * Kp), 256, 0, stream>>>(r.y_init, r.y0hat, guided ? r.x : nullptr, C, s->cat_y_pred,
-                                                                (guided && s->cat_x) ? s->x_dim : 0, Kp, r.n_z, N, w.S);
-    HIP_TRY(hipGetLastError());
+    CARD_LAUNCH(r, "wide_pack_state_kernel", false,
+                wide_pack_state_kernel<<<grid_for(N * Kp), 256, 0, stream>>>(r.y_init, r.y0hat, guided ? r.x : nullptr, C, s->cat_y_pred,
+                                                                            (guided && s->cat_x) ? s->x_dim : 0, Kp, r.n_z, N, w.S));
 
     if (r.eps_only) {
         const float* last = nullptr;
@@ -698,8 +671,7 @@ int wide_run_chunk(const card_sampler* s, const CardRun& r, long long stride, hi
             return head_fused(hp);
         }
         if (int rc = head_gemm(last)) return rc;
-        wide_copy_eps_kernel<<<grid_for(ne), 256, 0, stream>>>(w.eps, Cpad, C, ne, r.out);
-        HIP_TRY(hipGetLastError());
+        CARD_LAUNCH(r, "wide_copy_eps_kernel", false, wide_copy_eps_kernel<<<grid_for(ne), 256, 0, stream>>>(w.eps, Cpad, C, ne, r.out));
         return CARD_OK;
     }
     const int T = r.T;
@@ -708,9 +680,9 @@ int wide_run_chunk(const card_sampler* s, const CardRun& r, long long stride, hi
     const int* sel = r.out_mode == CARD_OUT_SELECT ? r.state_slot : nullptr;
     auto fixed = [&](int state) -> long long { return r.out_mode == CARD_OUT_ALL ? state - base : -1; };
     if (!r.y_init) {
-        wide_init_kernel<<<grid_for(ne), 256, 0, stream>>>(r.ytmean, r.noise, r.seed, r.elem_offset, ne, C, Kp, r.n_z, w.S,
-                                                          r.out, sel, fixed(0), stride);
-        HIP_TRY(hipGetLastError());
+        CARD_LAUNCH(r, "wide_init_kernel", false,
+                    wide_init_kernel<<<grid_for(ne), 256, 0, stream>>>(r.ytmean, r.noise, r.seed, r.elem_offset, ne, C, Kp, r.n_z, w.S,
+                                                                      r.out, sel, fixed(0), stride));
     }
     for (int t = r.t_hi; t >= r.t_lo; --t) {
         const float* last = nullptr;
@@ -724,14 +696,13 @@ int wide_run_chunk(const card_sampler* s, const CardRun& r, long long stride, hi
             continue;
         }
         if (int rc = head_gemm(last)) return rc;
-        wide_update_kernel<<<grid_for(ne), 256, 0, stream>>>(w.eps, Cpad, r.ytmean, r.coef + (size_t)t * CARD_COEF_COLS, nz,
-                                                            r.seed, r.elem_offset, draw, t, C, ne, Kp, r.n_z, w.S, r.out, sel, T - t,
-                                                            fixed(T - t), stride);
-        HIP_TRY(hipGetLastError());
+        CARD_LAUNCH(r, "wide_update_kernel", false,
+                    wide_update_kernel<<<grid_for(ne), 256, 0, stream>>>(w.eps, Cpad, r.ytmean, r.coef + (size_t)t * CARD_COEF_COLS, nz,
+                                                                        r.seed, r.elem_offset, draw, t, C, ne, Kp, r.n_z, w.S, r.out, sel, T - t,
+                                                                        fixed(T - t), stride));
     }
     if (r.out_mode == CARD_OUT_LAST) {
-        wide_copy_eps_kernel<<<grid_for(ne), 256, 0, stream>>>(w.S, Kp, C, ne, r.out);   // y_t columns of S -> (N, C)
-        HIP_TRY(hipGetLastError());
+        CARD_LAUNCH(r, "wide_copy_eps_kernel", false, wide_copy_eps_kernel<<<grid_for(ne), 256, 0, stream>>>(w.S, Kp, C, ne, r.out));   // y_t columns of S -> (N, C)
     }
     return CARD_OK;
 }
@@ -745,6 +716,11 @@ int wide_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     // chains per chunk: what the workspace holds, cut to whole 128-row GEMM tiles and whole input rows
     const size_t pc = per_chain_bytes(s);
     const int Cpad = (C + BN - 1) / BN * BN;
+    if (r.plan) {    // layer 1 with K padded to the state matrix's 32-column pitch, the F x F layers, lin4 fused (C columns) or as a GEMM padded to 128
+        const bool fused = C <= kHeadFusedMaxC && !s->tune.wide_gemmhead;
+        const int hidden_layers = s->variant == CARD_VARIANT_LINEAR_HADAMARD ? 1 : 2;
+        r.plan->executed = 2.0 * s->hidden * (state_ld(s) + hidden_layers * (double)s->hidden + (fused ? C : Cpad));
+    }
     const bool fits = carve(nullptr, N, s->hidden, state_ld(s), Cpad).bytes <= r.workspace_bytes;
     const long long cap = r.workspace_bytes > 4 * 256 ? (long long)((r.workspace_bytes - 4 * 256) / pc) : 0;   // 4 buffers, 256-B aligned
     long long chunk = N;

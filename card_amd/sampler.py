@@ -193,8 +193,10 @@ class Sampler:
 
     def run(self, x, y_0_hat, y_T_mean, coef, T, *, t_hi=None, t_lo=0, y_init=None, noise=None, seed=0,
             elem_offset=0, out_mode=_lib.OUT_LAST, states=None, n_z=1, static_scratch=False, fphi=None, fphi_out=None,
-            arith=_lib.ARITH_F32_MFMA):
+            arith=_lib.ARITH_F32_MFMA, plan=False):
         """card_sampler_run.  Returns (N, y_dim) for OUT_LAST, (n_states, N, y_dim) otherwise.
+        plan=True launches nothing and returns what card_sampler_plan reports for exactly this call: a dict with the
+        kernel that carries the flops, its launches, all launches, algorithmic and executed flops per sample-step.
         n_z > 1: x / y_0_hat / y_T_mean are per test ROW and every row is expanded to n_z chains inside the
         kernel (N = rows * n_z, chain order (row, z) like regression/card_regression.py:1027-1035).
         static_scratch=True goes through card_sampler_run_static: the kernels' scratch comes from the library's per-GPU
@@ -281,6 +283,13 @@ class Sampler:
         else:
             fn, what = L.card_sampler_run, "card_sampler_run"
             ws, a.workspace, a.workspace_bytes = self._workspace(N)
+        if plan:
+            pl = _lib.Plan()
+            pl.struct_bytes = C.sizeof(_lib.Plan)
+            _lib.check(L.card_sampler_plan(self._h, C.byref(a), C.byref(pl)), "card_sampler_plan")
+            return {"kernel": pl.kernel.decode(), "launches": pl.dominant_launches, "launches_all_kernels": pl.launches,
+                    "backend": pl.backend, "flops_per_sample_step": pl.flops_per_sample_step,
+                    "flops_executed_per_sample_step": pl.flops_executed_per_sample_step}
         if torch.cuda.current_device() == self.device.index:
             _lib.check(fn(self._h, C.byref(a), _stream(self.device)), what)
         else:

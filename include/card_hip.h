@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CARD_HIP_VERSION 210 /* major*10000 + minor*100 + patch */
+#define CARD_HIP_VERSION 300 /* major*10000 + minor*100 + patch */
 #define CARD_API __attribute__((visibility("default")))
 
 typedef enum card_status {
@@ -74,8 +74,8 @@ typedef enum card_arith {
        accumulation); the dropped terms are below 2^-24 |a||b|.  Measured error of a K = 128 dot product: below the
        FP32 MFMA chain's (tools/ubench/splitbf16.hip).  GUIDED samplers at hidden 128, y_dim 1 only (card_split.hip);
        CARD_E_UNSUPPORTED elsewhere.  Not bit-identical to CARD_ARITH_F32_MFMA (a different, equally accurate
-       rounding); same RNG streams.  The environment variable CARD_AMD_ARITH=split selects it for calls that leave
-       arith at 0. */
+       rounding); same RNG streams.  The environment variable CARD_AMD_ARITH=split (read when the sampler is created)
+       selects it for calls that leave arith at 0. */
     CARD_ARITH_SPLIT_BF16 = 1
 } card_arith;
 
@@ -205,6 +205,23 @@ typedef struct card_run_args {
  * p_sample_t_1to0 (:94-104) with t_hi = t_lo = 0. */
 CARD_API int card_sampler_run(const card_sampler* s, const card_run_args* args, void* stream);
 
+/* What a card_sampler_run call with these arguments WOULD launch, without launching or touching the device: a dry run of
+ * the same dispatch code (batch-size thresholds, time slices, chunking), so it cannot drift from it.  NO COUNTERPART IN
+ * THE REFERENCE; it exists so that a benchmark or a profiler script can name the kernel that carries the flops, count its
+ * launches and price the flops it issues without re-implementing the library's dispatch.  args as for card_sampler_run
+ * (validated the same way; pointers are not dereferenced). */
+typedef struct card_plan {
+    int32_t struct_bytes;            /* in: sizeof(card_plan) */
+    int32_t backend;                 /* 0 hidden-128 regression kernels, 1 GEMM back end, 2 streamed hidden-256 kernel, 3 cooperative classification kernel */
+    int32_t launches;                /* kernel launches of the call, all kinds */
+    int32_t dominant_launches;       /* of them, launches of `kernel` */
+    char kernel[96];                 /* the kernel that carries the matrix work (with its form) */
+    double flops_per_sample_step;          /* ALGORITHMIC: 2 H (d_in + 2 H + y_dim), SURVEY.md section 8d */
+    double flops_executed_per_sample_step; /* what the kernels issue: hoisted layer 1 once per tile and call, K / class padding priced in
+                                              (CARD_ARITH_SPLIT_BF16: the bf16 flops of its six partial products) */
+} card_plan;
+CARD_API int card_sampler_plan(const card_sampler* s, const card_run_args* args, card_plan* out);
+
 /* card_sampler_run for callers that cannot allocate device memory or pass a workspace: code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE.  Same arguments and results as
  * card_sampler_run (args->workspace / workspace_bytes are ignored); every scratch buffer -- the per-wave layer-1 slots of
@@ -214,7 +231,9 @@ CARD_API int card_sampler_run(const card_sampler* s, const card_run_args* args, 
  * nothing (no hipMalloc / hipFree, no allocating library routine).  Limits: on the GEMM back end the batch is walked in
  * chunks of as many chains as the array holds (12 483 at hidden 256, 1 004 at hidden 4096); if not even one input row's
  * n_z chains fit, the call fails with CARD_E_UNSUPPORTED.  All calls on one GPU share that GPU's array: calls that
- * overlap in time on one GPU (different streams or threads) race -- order them.  The sampler's device must be current. */
+ * overlap in time on one GPU (different streams or threads) race -- order them.  The sampler's device must be current.
+ * The FIRST call on a device looks the array's address up (hipGetSymbolAddress): a caller under HIP graph capture makes
+ * one call on that device before the capture begins. */
 #define CARD_STATIC_SCRATCH_BYTES (32u << 20)
 CARD_API int card_sampler_run_static(const card_sampler* s, const card_run_args* args, void* stream);
 

@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for n in names:
         assert hasattr(L, n), n
-    assert _lib.lib().card_version() == 210
+    assert _lib.lib().card_version() == 300
 
 
 def test_struct_sizes_match_header_layout(tmp_path):
@@ -35,12 +35,13 @@ def test_struct_sizes_match_header_layout(tmp_path):
     src = tmp_path / "sz.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "card_hip.h"\n'
-        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(card_model_desc), sizeof(card_run_args),'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(card_model_desc), sizeof(card_run_args),'
         ' offsetof(card_model_desc, W), offsetof(card_run_args, N), offsetof(card_run_args, out_mode),'
         ' offsetof(card_run_args, workspace_bytes), offsetof(card_run_args, fphi_out), sizeof(card_fphi_desc),'
         ' offsetof(card_fphi_desc, negative_slope), offsetof(card_fphi_desc, W), offsetof(card_fphi_desc, bn_shift),'
         ' sizeof(card_metric_args), sizeof(card_cls_metric_args), offsetof(card_cls_metric_args, rows),'
-        ' offsetof(card_cls_metric_args, scale_T), offsetof(card_cls_metric_args, sample_probs));'
+        ' offsetof(card_cls_metric_args, scale_T), offsetof(card_cls_metric_args, sample_probs),'
+        ' sizeof(card_plan), offsetof(card_plan, kernel), offsetof(card_plan, flops_executed_per_sample_step));'
         ' return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
@@ -49,7 +50,8 @@ def test_struct_sizes_match_header_layout(tmp_path):
     assert got == [ctypes.sizeof(M), ctypes.sizeof(R), M.W.offset, R.N.offset, R.out_mode.offset,
                    R.workspace_bytes.offset, R.fphi_out.offset, ctypes.sizeof(F), F.negative_slope.offset, F.W.offset,
                    F.bn_shift.offset, ctypes.sizeof(_lib.MetricArgs), ctypes.sizeof(CM), CM.rows.offset, CM.scale_T.offset,
-                   CM.sample_probs.offset]
+                   CM.sample_probs.offset, ctypes.sizeof(_lib.Plan), _lib.Plan.kernel.offset,
+                   _lib.Plan.flops_executed_per_sample_step.offset]
 
 
 def test_error_reporting_without_gpu():

@@ -45,9 +45,9 @@ def cuda(t):
 
 @pytest.fixture(params=["coop", "gemm"], autouse=True)
 def f128_kernel(request, monkeypatch):
-    """F = 128 heads run on the cooperative persistent kernel by default (card_clscoop.hip); CARD_AMD_CLSCOOP=0 (read
+    """F = 128 heads run on the cooperative persistent kernel by default (card_clscoop.hip); CARD_AMD_CLSCOOP=off (read
     when a sampler is created) keeps them on the GEMM back end.  Every test runs against both."""
-    monkeypatch.setenv("CARD_AMD_CLSCOOP", "1" if request.param == "coop" else "0")
+    monkeypatch.setenv("CARD_AMD_CLSCOOP", "" if request.param == "coop" else "off")
     return request.param
 
 
@@ -263,7 +263,7 @@ def test_f128_cooperative_kernel_equals_gemm_backend_in_rng_mode(monkeypatch):
         xf, y0 = cuda(g["x_feat"][idx]), cuda(g["y0hat"][idx])
         outs = []
         for mode in ("1", "0"):
-            monkeypatch.setenv("CARD_AMD_CLSCOOP", mode)
+            monkeypatch.setenv("CARD_AMD_CLSCOOP", "" if mode == "1" else "off")
             s = Sampler.from_cls_state_dict(g["sd"], guidance=guidance, device=DEV)
             assert (s._workspace(64)[2] == 0) == (mode == "1")      # the cooperative kernel needs no workspace
             outs.append(s.run(xf, y0, y0, coef, T, seed=31, elem_offset=12345, n_z=n_z, out_mode=_lib.OUT_SELECT,
@@ -334,12 +334,13 @@ def test_bn_model_in_train_mode_is_refused():
         card_amd.p_sample_loop(m.train(), *args, True, seed=1)
 
 
-@pytest.mark.parametrize("rows,n_z,C", [(250, 100, 10), (173, 97, 3), (40, 100, 10)])
-def test_f128_time_sliced_two_tile_form_is_bit_identical(rows, n_z, C, monkeypatch, f128_kernel):
-    """card_clscoop.hip: two tile positions per CU -- as two one-tile workgroups at 256 registers per wave (the default
-    "pair" form) or as one workgroup advancing two tiles (CARD_AMD_CLSCOOP_FORM=two) -- and the round-robin time slicing
-    (782 tiles = the MNIST test minibatch of 250 images x 100 z, classification/configs/mnist.yml) against the plain form
-    (one tile per workgroup, whole loops): same bits in every output mode, also through the entry point that allocates
+@pytest.mark.parametrize("rows,n_z,C", [(250, 100, 10), (173, 97, 3), (40, 100, 10), (120, 100, 20)])
+def test_f128_time_sliced_and_plain_forms_are_bit_identical(rows, n_z, C, monkeypatch, f128_kernel):
+    """card_clscoop.hip: the round-robin time slicing over two one-tile workgroups per CU (782 tiles = the MNIST test
+    minibatch of 250 images x 100 z, classification/configs/mnist.yml) against whole loops in one launch
+    (CARD_AMD_CLSCOOP=noslice, read when a sampler is created: the kernel then walks the tiles in rounds), and the compact
+    PAIR form (in-kernel row tiling, up to 16 classes) against the plain PAIR form (the same chains pre-tiled by the
+    caller, or more than 16 classes): same bits in every output mode, also through the entry point that allocates
     nothing."""
     if f128_kernel != "coop":
         pytest.skip("cooperative kernel only")
@@ -350,28 +351,30 @@ def test_f128_time_sliced_two_tile_form_is_bit_identical(rows, n_z, C, monkeypat
     y0 = cuda(torch.softmax(torch.randn(rows, C, generator=gen) * 2, 1))
     alphas, _, omabs = orc.make_schedule("linear", T, 1e-4, 0.1)
     coef = cuda(make_coef_table(alphas, omabs))
+    tiled = lambda t: t.repeat_interleave(n_z, 0).contiguous()          # chain order (row, z), as the reference tiles
     outs = {}
-    for name, g, sl, form in (("sliced2", "2", "1", "pair"), ("plain1", "1", "0", "pair"), ("sliced1", "1", "1", "pair"),
-                              ("plain2", "2", "0", "pair"), ("sliced2_two", "2", "1", "two"), ("plain2_two", "2", "0", "two")):
-        monkeypatch.setenv("CARD_AMD_CLSCOOP_G", g)
-        monkeypatch.setenv("CARD_AMD_CLSCOOP_SLICE", sl)
-        monkeypatch.setenv("CARD_AMD_CLSCOOP_FORM", form)
+    for name, env, pre in (("sliced", "", False), ("plain", "noslice", False), ("sliced_pretiled", "", True),
+                           ("plain_pretiled", "noslice", True)):
+        monkeypatch.setenv("CARD_AMD_CLSCOOP", env)
         s = Sampler.from_cls_state_dict(sd, device=DEV)
-        last = s.run(xf, y0, y0, coef, T, seed=12, elem_offset=3, n_z=n_z)
-        sel = s.run(xf, y0, y0, coef, T, seed=12, elem_offset=3, n_z=n_z, out_mode=_lib.OUT_SELECT, states=[0, 1, 64, 65, T])
-        seg = s.run(xf, y0, y0, coef, T, seed=12, elem_offset=3, n_z=n_z, t_hi=100, t_lo=7, y_init=sel[2])
+        a, b, nz = (tiled(xf), tiled(y0), 1) if pre else (xf, y0, n_z)
+        kw = dict(seed=12, elem_offset=3, n_z=nz)
+        last = s.run(a, b, b, coef, T, **kw)
+        sel = s.run(a, b, b, coef, T, out_mode=_lib.OUT_SELECT, states=[0, 1, 64, 65, T], **kw)
+        seg = s.run(a, b, b, coef, T, t_hi=100, t_lo=7, y_init=sel[2], **kw)
         outs[name] = (last, sel, seg)
-        if name == "sliced2":
-            assert torch.equal(s.run(xf, y0, y0, coef, T, seed=12, elem_offset=3, n_z=n_z, static_scratch=True), last)
-    for name in ("plain1", "sliced1", "plain2", "sliced2_two", "plain2_two"):
-        for a, b in zip(outs["sliced2"], outs[name]):
+        if name == "sliced":
+            form = s.run(a, b, b, coef, T, plan=True, **kw)["kernel"]
+            want = "ONE" if rows * n_z <= 256 * 32 else ("PAIR compact" if C <= 16 else "<PAIR>")      # 256 CUs
+            assert want in form, form
+            assert torch.equal(s.run(a, b, b, coef, T, static_scratch=True, **kw), last)
+    for name in ("plain", "sliced_pretiled", "plain_pretiled"):
+        for a, b in zip(outs["sliced"], outs[name]):
             assert torch.equal(a, b) and torch.isfinite(a).all(), name
-    assert torch.equal(outs["sliced2"][0], outs["sliced2"][1][-1])
+    assert torch.equal(outs["sliced"][0], outs["sliced"][1][-1])
     # and against the oracle under injected noise on the first and the last input row's chains
     w = orc.ClsWeights.from_state_dict(sd, guidance=True)
-    monkeypatch.setenv("CARD_AMD_CLSCOOP_G", "2")
-    monkeypatch.setenv("CARD_AMD_CLSCOOP_SLICE", "1")
-    monkeypatch.setenv("CARD_AMD_CLSCOOP_FORM", "pair")
+    monkeypatch.setenv("CARD_AMD_CLSCOOP", "")
     s = Sampler.from_cls_state_dict(sd, device=DEV)
     N = rows * n_z
     noise = torch.randn(T, N, C, generator=gen)
@@ -595,11 +598,13 @@ def test_imagenet_head_at_its_real_dimensions_against_oracle(F, C):
 
 
 @pytest.mark.parametrize("C", [1, 9, 16, 17, 32])
-def test_f128_two_workgroups_per_cu_form_over_class_counts(C, monkeypatch):
+def test_f128_two_workgroups_per_cu_form_over_class_counts(C, f128_kernel):
     """The default form above one tile per CU (two one-tile workgroups per CU at 256 registers per wave, lin1 / lin4
     fragments re-read from L2) at class counts on both sides of the 8-class groups and of the two lin4 forms: same bits
-    as the one-workgroup-per-CU form and as the two-tile workgroup, in RNG mode and for eps_theta, and <= 1e-4 from the
+    as the one-workgroup-per-CU form (the same chains in two calls of at most one tile per CU), in RNG mode and for eps_theta, and <= 1e-4 from the
     oracle under injected noise on the chains of the first and the last input row."""
+    if f128_kernel != "coop":
+        pytest.skip("cooperative kernel only")
     T, rows, n_z = 12, 90, 100                               # 9 000 chains = 282 tiles > 256 CUs
     sd = cls_state_dict(128, C, T, 11)
     gen = torch.Generator().manual_seed(C)
@@ -608,18 +613,20 @@ def test_f128_two_workgroups_per_cu_form_over_class_counts(C, monkeypatch):
     alphas, _, omabs = orc.make_schedule("linear", T, 1e-4, 0.3)
     coef = cuda(make_coef_table(alphas, omabs))
     outs = {}
-    for name, g, form in (("pair", "2", "pair"), ("single", "1", "pair"), ("two", "2", "two")):
-        monkeypatch.setenv("CARD_AMD_CLSCOOP_G", g)
-        monkeypatch.setenv("CARD_AMD_CLSCOOP_FORM", form)
-        s = Sampler.from_cls_state_dict(sd, device=DEV)
-        outs[name] = (s.run(xf, y0, y0, coef, T, seed=5, elem_offset=7, n_z=n_z, out_mode=_lib.OUT_ALL),
-                      s.eps_theta(xf.repeat_interleave(n_z, 0), y0.repeat_interleave(n_z, 0), y0.repeat_interleave(n_z, 0), 4))
-    for name in ("single", "two"):
-        assert torch.equal(outs["pair"][0], outs[name][0]) and torch.equal(outs["pair"][1], outs[name][1]), name
-    assert torch.isfinite(outs["pair"][0]).all()
-    monkeypatch.setenv("CARD_AMD_CLSCOOP_G", "2")
-    monkeypatch.setenv("CARD_AMD_CLSCOOP_FORM", "pair")
+    # the whole batch (282 tiles: PAIR forms, two workgroups per CU) against the same chains as two calls of 141 tiles
+    # each (at most one tile per CU: the ONE form, every fragment in registers), element offsets continuing
     s = Sampler.from_cls_state_dict(sd, device=DEV)
+    rep = lambda t: t.repeat_interleave(n_z, 0)
+    kw = dict(seed=5, n_z=n_z, out_mode=_lib.OUT_ALL)
+    whole = (s.run(xf, y0, y0, coef, T, elem_offset=7, **kw), s.eps_theta(rep(xf), rep(y0), rep(y0), 4))
+    h = rows // 2
+    assert "PAIR" in s.run(xf, y0, y0, coef, T, elem_offset=7, plan=True, **kw)["kernel"]
+    assert "ONE" in s.run(xf[:h], y0[:h], y0[:h], coef, T, elem_offset=7, plan=True, **kw)["kernel"]
+    halves = (torch.cat([s.run(xf[:h], y0[:h], y0[:h], coef, T, elem_offset=7, **kw),
+                         s.run(xf[h:], y0[h:], y0[h:], coef, T, elem_offset=7 + h * n_z * C, **kw)], 1),
+              torch.cat([s.eps_theta(rep(xf[:h]), rep(y0[:h]), rep(y0[:h]), 4), s.eps_theta(rep(xf[h:]), rep(y0[h:]), rep(y0[h:]), 4)], 0))
+    assert torch.equal(whole[0], halves[0]) and torch.equal(whole[1], halves[1])
+    assert torch.isfinite(whole[0]).all()
     w = orc.ClsWeights.from_state_dict(sd, guidance=True)
     N = rows * n_z
     noise = torch.randn(T, N, C, generator=gen)
@@ -633,10 +640,12 @@ def test_f128_two_workgroups_per_cu_form_over_class_counts(C, monkeypatch):
 
 
 @pytest.mark.parametrize("n_z", [31, 32, 33, 47])
-def test_f128_compact_form_at_the_edge_of_two_rows_per_tile(n_z, monkeypatch):
+def test_f128_compact_form_at_the_edge_of_two_rows_per_tile(n_z, f128_kernel):
     """The compact two-workgroup form keeps the hoisted layer-1 tile and x_feat as the TWO columns of the input rows a
     32-chain tile spans, which holds from n_z = 32 on (the host selects the plain form below that): same bits as the
     one-workgroup-per-CU form on both sides of that edge, every input row different, ragged last tile."""
+    if f128_kernel != "coop":
+        pytest.skip("cooperative kernel only")
     T, rows, C = 9, 301, 10                                   # > 8 192 chains, rows * n_z not a multiple of 32
     sd = cls_state_dict(128, C, T, 13)
     gen = torch.Generator().manual_seed(n_z)
@@ -645,9 +654,9 @@ def test_f128_compact_form_at_the_edge_of_two_rows_per_tile(n_z, monkeypatch):
     mu = cuda(torch.randn(rows, C, generator=gen))
     alphas, _, omabs = orc.make_schedule("linear", T, 1e-4, 0.3)
     coef = cuda(make_coef_table(alphas, omabs))
-    outs = []
-    for g in ("2", "1"):
-        monkeypatch.setenv("CARD_AMD_CLSCOOP_G", g)
-        s = Sampler.from_cls_state_dict(sd, device=DEV)
-        outs.append(s.run(xf, y0, mu, coef, T, seed=3, n_z=n_z, out_mode=_lib.OUT_ALL))
+    s = Sampler.from_cls_state_dict(sd, device=DEV)
+    kw = dict(seed=3, n_z=n_z, out_mode=_lib.OUT_ALL)
+    per = max(1, 8192 // n_z)                                 # rows per call that stay within one tile per CU: the ONE form
+    parts = [s.run(xf[r:r + per], y0[r:r + per], mu[r:r + per], coef, T, elem_offset=r * n_z * C, **kw) for r in range(0, rows, per)]
+    outs = [s.run(xf, y0, mu, coef, T, **kw), torch.cat(parts, 1)]
     assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])

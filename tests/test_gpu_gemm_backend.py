@@ -87,14 +87,13 @@ def test_chunked_run_equals_unchunked(n_z, monkeypatch):
                                           (256, 17, 31, 9), (128, 32, 65, 2)])
 def test_fused_head_update_equals_gemm_head(F, C, rows, n_z, monkeypatch):
     """wide_head_update_kernel (lin4 + posterior update in one VALU launch, classes <= 32) against the head as a GEMM launch
-    + wide_update_kernel (CARD_AMD_WIDE_HEAD=gemm): same states to rounding (the dot products are associated differently),
+    + wide_update_kernel (CARD_AMD_WIDE=gemmhead, read when a sampler is created): same states to rounding (the dot products are associated differently),
     y_T bit-equal, eps_theta to rounding; class counts at the edges of the kernel's 8 / 16 / 32 paddings, a feature width
     that is an odd multiple of 128, ragged row groups."""
     from card_amd.synth import cls_state_dict
     from card_amd.synth import make_schedule
-    monkeypatch.setenv("CARD_AMD_CLSCOOP", "0")
+    monkeypatch.setenv("CARD_AMD_CLSCOOP", "off")
     T = 12
-    s = Sampler.from_cls_state_dict(cls_state_dict(F, C, T, 5), device=DEV)
     g = torch.Generator().manual_seed(C * 1000 + F)
     xf = cuda(torch.randn(rows, F, generator=g))
     y0 = cuda(torch.softmax(torch.randn(rows, C, generator=g) * 2, 1))
@@ -102,7 +101,8 @@ def test_fused_head_update_equals_gemm_head(F, C, rows, n_z, monkeypatch):
     coef = cuda(make_coef_table(alphas, omabs))
     outs = {}
     for head in ("fused", "gemm"):
-        monkeypatch.setenv("CARD_AMD_WIDE_HEAD", head)
+        monkeypatch.setenv("CARD_AMD_WIDE", "" if head == "fused" else "gemmhead")
+        s = Sampler.from_cls_state_dict(cls_state_dict(F, C, T, 5), device=DEV)
         outs[head] = (s.run(xf, y0, y0, coef, T, seed=4, elem_offset=11, n_z=n_z, out_mode=_lib.OUT_ALL),
                       s.eps_theta(xf, y0, y0, 3))
     a, b = outs["fused"], outs["gemm"]
@@ -117,12 +117,11 @@ def test_fused_head_update_equals_gemm_head(F, C, rows, n_z, monkeypatch):
 @pytest.mark.parametrize("F,rows,n_z", [(256, 300, 7), (1024, 1000, 3), (128, 4000, 1)])
 def test_tail_tiles_change_no_bits(F, rows, n_z, monkeypatch):
     """The last, partly filled round of a GEMM launch runs as 64 x 64 tiles (wide_gemm_tile<.., 64, 64>): every output
-    element is the same fp32 FMA chain over k as in a 128 x 128 tile, so CARD_AMD_WIDE_TAIL=0 gives the same bits."""
+    element is the same fp32 FMA chain over k as in a 128 x 128 tile, so CARD_AMD_WIDE=notail gives the same bits."""
     from card_amd.synth import cls_state_dict
     from card_amd.synth import make_schedule
-    monkeypatch.setenv("CARD_AMD_CLSCOOP", "0")
+    monkeypatch.setenv("CARD_AMD_CLSCOOP", "off")
     T, C = 10, 10
-    s = Sampler.from_cls_state_dict(cls_state_dict(F, C, T, 6), device=DEV)
     g = torch.Generator().manual_seed(F)
     xf = cuda(torch.randn(rows, F, generator=g))
     y0 = cuda(torch.softmax(torch.randn(rows, C, generator=g) * 2, 1))
@@ -130,6 +129,7 @@ def test_tail_tiles_change_no_bits(F, rows, n_z, monkeypatch):
     coef = cuda(make_coef_table(alphas, omabs))
     outs = []
     for tail in ("1", "0"):
-        monkeypatch.setenv("CARD_AMD_WIDE_TAIL", tail)
+        monkeypatch.setenv("CARD_AMD_WIDE", "" if tail == "1" else "notail")
+        s = Sampler.from_cls_state_dict(cls_state_dict(F, C, T, 6), device=DEV)
         outs.append(s.run(xf, y0, y0, coef, T, seed=8, n_z=n_z, out_mode=_lib.OUT_ALL))
     assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])

@@ -58,8 +58,8 @@ def _need_gpu():
 @pytest.fixture(params=["coop", "persistent"], autouse=True)
 def small_batch_kernel(request, monkeypatch):
     """Every test runs twice: with the cooperative small-batch kernel (the default below ~24 000 chains) and with it
-    switched off (CARD_AMD_COOP=0, read when a sampler is created), so the fixtures pin both kernels."""
-    monkeypatch.setenv("CARD_AMD_COOP", "1" if request.param == "coop" else "0")
+    switched off (CARD_AMD_COOP=off, read when a sampler is created), so the fixtures pin both kernels."""
+    monkeypatch.setenv("CARD_AMD_COOP", "" if request.param == "coop" else "off")
     return request.param
 
 
@@ -140,21 +140,16 @@ def test_q_sample_bit_exact(name):
     assert torch.equal(out, torch.from_numpy(d["q.out"]))
 
 
-def test_hoisted_layer1_equals_lds_resident_layer1(monkeypatch):
-    """CARD_AMD_HOIST=1 forces the any-d_in kernel (layer-1 static part hoisted to a per-wave scratch slot) on a
-    model the LDS-resident kernel also covers: both must meet the parity bar and agree closely with each other."""
+def test_hoisted_layer1_slots_are_reused_across_tiles():
+    """The persistent kernel's hoisted layer-1 tile (static part computed once per tile into a per-wave scratch slot) on
+    the cat variants: parity with the reference, and many tiles per wave give every copy of a chain the same bits."""
     for name in ("reg_boston_T50", "reg_toy_T50", "reg_yonly_T50", "reg_nocaty_T50"):
         g = load_golden(name)
         kw = dict(cat_x=g["cat_x"], cat_y_pred=g["cat_y_pred"], device=DEV)
-        monkeypatch.setenv("CARD_AMD_HOIST", "0")
-        a = Sampler.from_state_dict(g["sd"], **kw)
-        monkeypatch.setenv("CARD_AMD_HOIST", "1")
         b = Sampler.from_state_dict(g["sd"], **kw)
-        ra = _raw_run(a, g, noise=cuda(g["noise"]), out_mode=_lib.OUT_ALL).cpu()
         rb = _raw_run(b, g, noise=cuda(g["noise"]), out_mode=_lib.OUT_ALL).cpu()
         ref = g["traj"]
         assert max(norm_rel_err(rb[k], ref[i]) for i, k in enumerate(g["traj_idx"])) <= TOL
-        assert norm_rel_err(rb, ra) <= 1e-5
         # many tiles per wave: slot reuse across tiles
         reps = 700
         big = _raw_run(b, g, N_rep=reps, noise=cuda(g["noise"].repeat(1, reps, 1))).cpu().reshape(reps, -1, 1)
@@ -376,7 +371,7 @@ def test_cooperative_kernel_many_tiles_per_workgroup(monkeypatch):
     g = load_golden("reg_boston_T50")
     reps = 1000
     outs = []
-    for mode in ("2", "0"):                               # cooperative forced / switched off
+    for mode in ("force", "off"):                         # cooperative forced / switched off
         monkeypatch.setenv("CARD_AMD_COOP", mode)
         s = Sampler.from_state_dict(g["sd"], cat_x=g["cat_x"], cat_y_pred=g["cat_y_pred"], device=DEV)
         outs.append(_raw_run(s, g, N_rep=reps, seed=17, out_mode=_lib.OUT_SELECT, states=[0, 10, g["T"]]))

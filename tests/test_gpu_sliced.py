@@ -1,7 +1,7 @@
 """The time-sliced paired cooperative kernel (card_sample_coop2_kernel, card_guided.hip): between one and two 32-chain
 tiles per CU (the reference's Year minibatch, 64 rows x 200 z = 12 800 chains, regression/configs/uci_year.yml:62,67)
 the loop is cut into slices in which every CU is busy, with chain states handed over in global memory between the
-launches.  Bar: bit-identical to the un-sliced kernels (CARD_AMD_COOP2=0) in every output mode, and within 1e-4 of the
+launches.  Bar: bit-identical to the un-sliced kernels (CARD_AMD_COOP=no2, read when a sampler is created) in every output mode, and within 1e-4 of the
 oracle under injected noise on slices of the batch."""
 import pytest
 import torch
@@ -33,15 +33,14 @@ def _inputs(g, rows, seed):
 @pytest.mark.parametrize("N", [12800, 9001, 8224, 14336])
 def test_sliced_equals_unsliced_bit_for_bit(N, monkeypatch):
     assert 1.0 < _tiles_per_cu(N) < 2.0, "sized for a 256-CU MI355X"
-    monkeypatch.setenv("CARD_AMD_COOP16", "0")       # keep these sizes on the 32-chain kernels
     g = load_golden("reg_boston_T1000")
-    s = Sampler.from_state_dict(g["sd"], device=DEV)
     T = 200                                   # the first 200 timesteps' schedule rows of the T = 1000 model
     coef = make_coef_table(g["alphas"][:T], g["omabs"][:T]).to(DEV)
     x, y0, mu = _inputs(g, N, 3)
     outs = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("CARD_AMD_COOP2", mode)
+        monkeypatch.setenv("CARD_AMD_COOP", "no16" if mode == "1" else "no16,no2")       # keep these sizes on the 32-chain kernels
+        s = Sampler.from_state_dict(g["sd"], device=DEV)
         last = s.run(x, y0, mu, coef, T, seed=21, elem_offset=7)
         sel = s.run(x, y0, mu, coef, T, seed=21, elem_offset=7, out_mode=_lib.OUT_SELECT, states=[0, 1, 57, 58, 120, T - 1, T])
         # a segment that starts in the middle of the loop from a given state (p_sample_loop_with_eval's segments)
@@ -51,7 +50,8 @@ def test_sliced_equals_unsliced_bit_for_bit(N, monkeypatch):
         assert torch.equal(a, b) and torch.isfinite(a).all()
     assert torch.equal(outs["1"][0], outs["1"][1][-1])
     # the entry point that allocates nothing takes the hand-over buffer from the library's static array
-    monkeypatch.setenv("CARD_AMD_COOP2", "1")
+    monkeypatch.setenv("CARD_AMD_COOP", "no16")
+    s = Sampler.from_state_dict(g["sd"], device=DEV)
     assert torch.equal(s.run(x, y0, mu, coef, T, seed=21, elem_offset=7, static_scratch=True), outs["0"][0])
 
 
@@ -59,7 +59,6 @@ def test_sliced_full_trajectory_and_row_tiling_vs_oracle(monkeypatch):
     """OUT_ALL with injected noise, rows tiled in-kernel (64 rows x 200 z like uci_year.yml): every state equals the
     un-sliced run bit for bit, and the chains of the first and last rows match the oracle."""
     g = load_golden("reg_year_T1000")
-    s = Sampler.from_state_dict(g["sd"], device=DEV)
     T, rows, n_z = 80, 64, 200
     alphas, _, omabs = orc.make_schedule("linear", T, 1e-4, 0.25)
     coef = make_coef_table(alphas, omabs).to(DEV)
@@ -68,7 +67,8 @@ def test_sliced_full_trajectory_and_row_tiling_vs_oracle(monkeypatch):
     noise = torch.randn(T, N, 1, generator=torch.Generator().manual_seed(9))
     outs = []
     for mode in ("1", "0"):
-        monkeypatch.setenv("CARD_AMD_COOP2", mode)
+        monkeypatch.setenv("CARD_AMD_COOP", "" if mode == "1" else "no2")
+        s = Sampler.from_state_dict(g["sd"], device=DEV)
         outs.append(s.run(x, y0, mu, coef, T, noise=noise.to(DEV), out_mode=_lib.OUT_ALL, n_z=n_z))
     assert torch.equal(outs[0], outs[1])
     w = g["weights"]
@@ -91,10 +91,8 @@ def test_16_chain_tile_kernel_is_bit_identical_to_the_32_chain_kernels(N, monkey
     coef = make_coef_table(g["alphas"][:T], g["omabs"][:T]).to(DEV)
     x, y0, mu = _inputs(g, N, 11)
     outs = {}
-    for name, env in (("coop16", {"CARD_AMD_COOP16": "1"}), ("coop32", {"CARD_AMD_COOP16": "0", "CARD_AMD_COOP2": "0"}),
-                      ("persistent", {"CARD_AMD_COOP": "0"})):
-        for k in ("CARD_AMD_COOP16", "CARD_AMD_COOP2", "CARD_AMD_COOP"):
-            monkeypatch.delenv(k, raising=False)
+    for name, env in (("coop16", {}), ("coop32", {"CARD_AMD_COOP": "no16,no2"}), ("persistent", {"CARD_AMD_COOP": "off"})):
+        monkeypatch.delenv("CARD_AMD_COOP", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         s = Sampler.from_state_dict(g["sd"], device=DEV)
@@ -121,8 +119,7 @@ def test_16_chain_tile_kernel_year_width_and_row_tiling(monkeypatch):
     noise = torch.randn(T, rows * n_z, 1, generator=torch.Generator().manual_seed(14))
     outs = []
     for mode in ("1", "0"):
-        monkeypatch.setenv("CARD_AMD_COOP16", mode)
-        monkeypatch.setenv("CARD_AMD_COOP2", mode)
+        monkeypatch.setenv("CARD_AMD_COOP", "" if mode == "1" else "no16,no2")
         s = Sampler.from_state_dict(g["sd"], device=DEV)
         outs.append(s.run(x, y0, mu, coef, T, noise=noise.to(DEV), out_mode=_lib.OUT_ALL, n_z=n_z))
     assert torch.equal(outs[0], outs[1])

@@ -26,8 +26,8 @@ def cuda(t):
 @pytest.fixture(params=["small4", "full8"], autouse=True)
 def wave_form(request, monkeypatch):
     """Batches of at most num_cu * 64 chains run with four waves per workgroup (one per SIMD) by default;
-    CARD_AMD_STREAM_SMALL=0 (read per call) keeps the 8-wave form.  Every test runs against both."""
-    monkeypatch.setenv("CARD_AMD_STREAM_SMALL", "1" if request.param == "small4" else "0")
+    CARD_AMD_STREAM=big (read when a sampler is created) keeps the 8-wave form.  Every test runs against both."""
+    monkeypatch.setenv("CARD_AMD_STREAM", "" if request.param == "small4" else "big")
     return request.param
 
 
@@ -100,11 +100,9 @@ def test_stream_kernel_row_tiling_and_many_groups():
     a = s.run(cuda(x), cuda(y0), cuda(mu), coef, T, seed=8, n_z=n_z)
     b = s.run(cuda(tile_rows(x, n_z)), cuda(tile_rows(y0, n_z)), cuda(tile_rows(mu, n_z)), coef, T, seed=8)
     assert a.shape == (rows * n_z, 1) and torch.equal(a, b)
-    os.environ["CARD_AMD_STREAM"] = "0"
-    try:
+    with pytest.MonkeyPatch.context() as mp:
+        mp.setenv("CARD_AMD_STREAM", "off")
         sg = Sampler.from_state_dict(sd, device=DEV)      # same weights on the GEMM back end
-    finally:
-        del os.environ["CARD_AMD_STREAM"]
     c = sg.run(cuda(x), cuda(y0), cuda(mu), coef, T, seed=8, n_z=n_z)
     err = norm_rel_err(a.cpu(), c.cpu())
     print(f"stream vs GEMM back end, 40k chains: {err:.3e}")
@@ -119,11 +117,9 @@ def test_stream_kernel_several_launches():
     s = Sampler.from_state_dict(sd, device=DEV)
     coef = cuda(make_coef_table(alphas, omabs))
     a = s.run(cuda(x), cuda(y0), cuda(mu), coef, T, seed=4, n_z=n_z)
-    os.environ["CARD_AMD_STREAM"] = "0"
-    try:
+    with pytest.MonkeyPatch.context() as mp:
+        mp.setenv("CARD_AMD_STREAM", "off")
         sg = Sampler.from_state_dict(sd, device=DEV)
-    finally:
-        del os.environ["CARD_AMD_STREAM"]
     b = sg.run(cuda(x), cuda(y0), cuda(mu), coef, T, seed=4, n_z=n_z)
     assert a.shape == (rows * n_z, 1) and torch.isfinite(a).all()
     assert norm_rel_err(a.cpu(), b.cpu()) <= TOL
@@ -133,10 +129,10 @@ def test_stream_kernel_several_launches():
 def test_four_wave_and_eight_wave_forms_agree_bit_for_bit(N, monkeypatch):
     T = 7
     sd, x, y0, mu, _, alphas, omabs = _case(13, T, N, 77)
-    s = Sampler.from_state_dict(sd, device=DEV)
     coef = cuda(make_coef_table(alphas, omabs))
     outs = []
     for small in ("1", "0"):
-        monkeypatch.setenv("CARD_AMD_STREAM_SMALL", small)
+        monkeypatch.setenv("CARD_AMD_STREAM", "" if small == "1" else "big")
+        s = Sampler.from_state_dict(sd, device=DEV)
         outs.append(s.run(cuda(x), cuda(y0), cuda(mu), coef, T, seed=3, out_mode=_lib.OUT_ALL))
     assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0]).all()
