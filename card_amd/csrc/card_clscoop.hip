@@ -510,6 +510,8 @@ __global__ __launch_bounds__(kThreads, FORM >= 1 ? 2 : 1) void card_sample_cls_c
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             if (!on[g]) continue;
+            gcur[g] ^= more[g] ? 1 : 0;
+            if (COMPACT && !ys_owner) continue;            // up to 16 classes: waves 2 and 3 own none (wave-uniform)
             const int t = th[g] - it;
             f32x4 eps = lds4(red[g] + m * YL + c0);
 #pragma unroll
@@ -518,7 +520,6 @@ __global__ __launch_bounds__(kThreads, FORM >= 1 ? 2 : 1) void card_sample_cls_c
                 eps += v;
             }
             eps += b4v;
-            gcur[g] ^= more[g] ? 1 : 0;
             if (p.eps_only) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
