@@ -264,6 +264,7 @@ static int sampler_run(const card_sampler* s, const card_run_args* a, void* stre
     }
     if (!y0hat || !ytmean || !a->coef || !a->out)
         return fail(CARD_E_INVALID, "card_sampler_run: null y_0_hat / y_T_mean / coef / out");
+    if (((uintptr_t)a->coef & 15) != 0) return fail(CARD_E_INVALID, "card_sampler_run: coef must be 16-byte aligned (rows are read as two 16-byte loads)");
     const bool need_x = s->variant != CARD_VARIANT_GUIDED || (s->cat_x && s->x_dim > 0);
     if (need_x && !a->x) return fail(CARD_E_INVALID, "card_sampler_run: x is NULL but the model reads x");
     if (a->out_mode == CARD_OUT_SELECT && !a->state_slot) return fail(CARD_E_INVALID, "card_sampler_run: CARD_OUT_SELECT needs state_slot");

@@ -120,6 +120,25 @@ __device__ __forceinline__ void epilogue_tile(f32x16& acc, const float* gl, int 
     __builtin_amdgcn_s_setprio(kPrioMfma);
 }
 
+// One row of the (T, 8) coefficient table, requested at the TOP of a timestep: asked for where it is used (after lin4) the
+// load sat in the dependent chain of every timestep with its full L2 latency -- twice, the second half of the row behind
+// the t >= 1 branch (ISA of round 2's kernels).
+struct CoefRow { float inv_sab, om_sab, somab, g0, g1, g2, sigma; };
+__device__ __forceinline__ CoefRow load_coef(const float* coef, int t) {
+    const float* c = coef + (long long)t * CARD_COEF_COLS;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(c);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(c + 4);
+    return {a[CARD_COEF_INV_SQRT_AB], a[CARD_COEF_ONE_M_SQRT_AB], a[CARD_COEF_SOMAB], a[CARD_COEF_G0],
+            b[CARD_COEF_G1 - 4], b[CARD_COEF_G2 - 4], b[CARD_COEF_SIGMA - 4]};
+}
+// posterior update, regression/diffusion_utils.py:83-89 (t >= 1) / :101-103 (t == 0), unfused fp32 in the reference's order
+__device__ __forceinline__ float posterior_update(const CoefRow& c, int t, float y, float mu, float eps, float z) {
+    const float y0r = c.inv_sab * ((y - c.om_sab * mu) - eps * c.somab);
+    if (t < 1) return y0r;
+    const float yh = (c.g0 * y0r + c.g1 * y) + c.g2 * mu;
+    return yh + c.sigma * z;
+}
+
 __device__ __forceinline__ void load_bias(f32x16& acc, const float* bl, int j) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -326,6 +345,8 @@ __global__ __launch_bounds__(kThreads, 2) void card_sample_guided_kernel(const R
                 for (int i = 0; i < 6; ++i) gn[i] = p.gtab[(long long)(t - 1) * kGammaRow + i * 64 + lane];
             }
             const float z = t >= 1 && !p.eps_only ? draw(T - t) : 0.0f;
+            CoefRow cf = {};
+            if (!p.eps_only) cf = load_coef(p.coef, t);        // (card_eps_theta passes no table)
 
             f32x16 hA[4], hB[4];
             if constexpr (HOIST == 1) {
@@ -361,15 +382,7 @@ __global__ __launch_bounds__(kThreads, 2) void card_sample_guided_kernel(const R
                 break;
             }
 
-            // posterior update, regression/diffusion_utils.py:83-89 (t >= 1) / :101-103 (t == 0)
-            const float* c = p.coef + (long long)t * CARD_COEF_COLS;
-            const float y0r = c[CARD_COEF_INV_SQRT_AB] * ((y - c[CARD_COEF_ONE_M_SQRT_AB] * mu) - eps * c[CARD_COEF_SOMAB]);
-            if (t >= 1) {
-                const float yh = (c[CARD_COEF_G0] * y0r + c[CARD_COEF_G1] * y) + c[CARD_COEF_G2] * mu;
-                y = yh + c[CARD_COEF_SIGMA] * z;
-            } else {
-                y = y0r;
-            }
+            y = posterior_update(cf, t, y, mu, eps, z);
             store_state(T - t, y);
 
             __builtin_amdgcn_wave_barrier();
@@ -524,6 +537,8 @@ __global__ __launch_bounds__(kCoopThreads, 2) void card_sample_coop_kernel(const
             f32x4 gn = {0.f, 0.f, 0.f, 0.f};
             if (more && tid < kGammaRow / 4) gn = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(t - 1) * kGammaRow + tid * 4);
             const bool noisy = t >= 1 && !p.eps_only;
+            CoefRow cf = {};
+            if (!p.eps_only) cf = load_coef(p.coef, t);
             if (noisy) zfill(T - t);
             const float* const gl = gsl + gcur * kGammaRow + 4 * hh;
 
@@ -556,14 +571,7 @@ __global__ __launch_bounds__(kCoopThreads, 2) void card_sample_coop_kernel(const
                 if (valid && hh == 0 && w == 0) p.out[row] = eps;
                 break;
             }
-            const float* c = p.coef + (long long)t * CARD_COEF_COLS;
-            const float y0r = c[CARD_COEF_INV_SQRT_AB] * ((y - c[CARD_COEF_ONE_M_SQRT_AB] * mu) - eps * c[CARD_COEF_SOMAB]);
-            if (t >= 1) {
-                const float yh = (c[CARD_COEF_G0] * y0r + c[CARD_COEF_G1] * y) + c[CARD_COEF_G2] * mu;
-                y = yh + c[CARD_COEF_SIGMA] * z;
-            } else {
-                y = y0r;
-            }
+            y = posterior_update(cf, t, y, mu, eps, z);
             store_state(T - t, y);
         }
         if (p.out_mode == CARD_OUT_LAST && !p.eps_only && valid && hh == 0 && w == 0) p.out[row] = y;
@@ -736,8 +744,10 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop2_kernel(con
         f32x4 gn = {0.f, 0.f, 0.f, 0.f};
         float z = 0.0f;
         f32x16 acc;
+        CoefRow cf = {};
         const float* const gl = gsl + gcur * kGammaRow + 4 * hh;
         if (on) {
+            if (!p.eps_only) cf = load_coef(p.coef, t);
             if (more && htid < kGammaRow / 4) gn = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(t - 1) * kGammaRow + htid * 4);
             if (t >= 1 && !p.eps_only) zfill(T - t);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a10, hh == 0 ? y : 0.0f, c1, 0, 0, 0);
@@ -771,14 +781,7 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop2_kernel(con
             if (p.eps_only) {
                 if (valid && hh == 0 && w == 0) p.out[row] = eps;
             } else {
-                const float* c = p.coef + (long long)t * CARD_COEF_COLS;
-                const float y0r = c[CARD_COEF_INV_SQRT_AB] * ((y - c[CARD_COEF_ONE_M_SQRT_AB] * mu) - eps * c[CARD_COEF_SOMAB]);
-                if (t >= 1) {
-                    const float yh = (c[CARD_COEF_G0] * y0r + c[CARD_COEF_G1] * y) + c[CARD_COEF_G2] * mu;
-                    y = yh + c[CARD_COEF_SIGMA] * z;
-                } else {
-                    y = y0r;
-                }
+                y = posterior_update(cf, t, y, mu, eps, z);
                 store_state(T - t, y);
             }
         }
@@ -810,15 +813,16 @@ constexpr int kHalf16LdsFloats = 2 * kT16 * kExLd + kCoopWaves * kT16 + 2 * kGam
 constexpr int kCoop16LdsFloats = 2 * kHalf16LdsFloats + kTabFloats;
 constexpr int kImg16Floats = 2 * kH * kH;                 // W2 | W3 in 16x16x4 fragment order
 
-// gamma multiply + softplus of this wave's 32 features x 16 chains (two 16-feature accumulator blocks), staged
-__device__ __forceinline__ void epilogue16(f32x4 (&acc)[2], const float* gl) {
+// gamma multiply + softplus of this wave's 32 features x 16 chains (two 16-feature accumulator blocks), staged.  The
+// gamma values arrive in registers: the caller reads them from LDS BEFORE the layer's MFMAs, so their LDS latency is
+// covered by the matrix work instead of being waited out at the head of every epilogue (a lone wave per SIMD hides nothing)
+__device__ __forceinline__ void epilogue16(f32x4 (&acc)[2], const f32x4 (&gm)[2]) {
     float xs[8], e[8];
     __builtin_amdgcn_s_setprio(kPrioValu);
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
-        const f32x4 g = lds4(gl + 16 * mb);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) xs[4 * mb + k] = acc[mb][k] * g[k];
+        for (int k = 0; k < 4; ++k) xs[4 * mb + k] = acc[mb][k] * gm[mb][k];
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -891,6 +895,15 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
     float a10[2];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) a10[mb] = g == 0 ? tab[(kOffW1 - kOffB) + 32 * w + 16 * mb + n] : 0.0f;
+    // loop-invariant LDS tables this lane needs every timestep, held in registers (LDS reads are not hoisted over the
+    // loop's barriers by the compiler, and a read placed next to its use costs a full LDS latency in the dependent chain)
+    f32x4 w4r[2], bias2[2], bias3[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        w4r[mb] = lds4(w4l + 16 * mb);
+        bias2[mb] = lds4(tb + kH + 16 * mb);
+        bias3[mb] = lds4(tb + 2 * kH + 16 * mb);
+    }
     // Exchange tile, row n = chain: the four B operands (j = 0..3) that lane group gc consumes for MFMAs 4a .. 4a + 3 sit
     // at float 64 (gc & 1) + 8a + 4 (gc >> 1) + j.  A ds_read_b128 is served in 16-lane groups that hold every chain n
     // once, from lane groups {0, 1} or {2, 3}: the two groups of a pair are 64 floats = one whole bank row apart, so the
@@ -992,9 +1005,13 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
             *reinterpret_cast<f32x4*>(exw + buf * kT16 * kExLd + 8 * mb) = v;
         }
     };
-    auto hidden = [&](const float (&A)[64], int buf, int layer, const float* gl, f32x4 (&acc)[2]) {
+    auto hidden = [&](const float (&A)[64], int buf, int layer, const float* gl, const f32x4 (&bias)[2], f32x4 (&acc)[2]) {
+        f32x4 gm[2];
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) acc[mb] = lds4(tb + layer * kH + 16 * mb);
+        for (int mb = 0; mb < 2; ++mb) {
+            acc[mb] = bias[mb];
+            gm[mb] = lds4(gl + layer * kH + 32 * w + 16 * mb);       // used after the MFMAs
+        }
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
             const f32x4 h = lds4(exr + buf * kT16 * kExLd + 8 * a);
@@ -1004,7 +1021,7 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
                 acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[32 + 4 * a + e], h[e], acc[1], 0, 0, 0);
             }
         }
-        epilogue16(acc, gl + layer * kH + 32 * w);
+        epilogue16(acc, gm);
     };
 
     for (int it = 0; it < n_iter; ++it) {
@@ -1014,24 +1031,29 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
         f32x4 gn = {0.f, 0.f, 0.f, 0.f};
         float z = 0.0f;
         f32x4 acc[2];
+        CoefRow cf = {};
         const float* const gl = gsl + gcur * kGammaRow + 4 * g;
         if (on) {
+            if (!p.eps_only) cf = load_coef(p.coef, t);
             if (more && htid < kGammaRow / 4) gn = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(t - 1) * kGammaRow + htid * 4);
+            f32x4 gm1[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) gm1[mb] = lds4(gl + 32 * w + 16 * mb);
             if (t >= 1 && !p.eps_only) zfill(T - t);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a10[mb], g == 0 ? y : 0.0f, c1[mb], 0, 0, 0);
-            epilogue16(acc, gl + 32 * w);
+            epilogue16(acc, gm1);
             publish(acc, 0);
         }
         __syncthreads();
         if (on) {
             z = t >= 1 && !p.eps_only ? draw(T - t) : 0.0f;
-            hidden(A2, 0, 1, gl, acc);
+            hidden(A2, 0, 1, gl, bias2, acc);
             publish(acc, 1);
         }
         __syncthreads();
         if (on) {
-            hidden(A3, 1, 2, gl, acc);
+            hidden(A3, 1, 2, gl, bias3, acc);
             if (more && htid < kGammaRow / 4) *reinterpret_cast<f32x4*>(gsl + (gcur ^ 1) * kGammaRow + htid * 4) = gn;
             // lin4 in the 32-chain kernels' association: the chain over features 8q + e (q, e ascending) lives on lane
             // groups 0 -> 2 -> 0 -> 2, the one over 8q + 4 + e on 1 -> 3 -> 1 -> 3; each finished chain is added to the other
@@ -1045,11 +1067,17 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
                     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(px), "+v"(py));
                     part = (ph & 1) ? px : py;          // odd: lanes 32-63 receive; even: lanes 0-31 receive
                 }
-                const f32x4 wv = lds4(w4l + 16 * (ph >> 1));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) part = fmaf(acc[ph >> 1][e], wv[e], part);
+                for (int e = 0; e < 4; ++e) part = fmaf(acc[ph >> 1][e], w4r[ph >> 1][e], part);
             }
-            part += __shfl_xor(part, 16, 64);
+            // part + (part of lane ^ 16): v_permlane16_swap trades the odd 16-lane rows of its first operand with the even
+            // rows of its second, so two copies of part become (row 0, row 0, row 2, row 2) and (row 1, row 1, row 3, row 3);
+            // their sum is what part += __shfl_xor(part, 16) gives (fp32 addition commutes) without its LDS round trip
+            {
+                float pa = part, pb = part;
+                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(pa), "+v"(pb));
+                part = pa + pb;
+            }
             if (g == 2) red[w * kT16 + n] = part;
         }
         __syncthreads();
@@ -1059,14 +1087,7 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
             if (p.eps_only) {
                 if (valid && g == 0 && w == 0) p.out[row] = eps;
             } else {
-                const float* c = p.coef + (long long)t * CARD_COEF_COLS;
-                const float y0r = c[CARD_COEF_INV_SQRT_AB] * ((y - c[CARD_COEF_ONE_M_SQRT_AB] * mu) - eps * c[CARD_COEF_SOMAB]);
-                if (t >= 1) {
-                    const float yh = (c[CARD_COEF_G0] * y0r + c[CARD_COEF_G1] * y) + c[CARD_COEF_G2] * mu;
-                    y = yh + c[CARD_COEF_SIGMA] * z;
-                } else {
-                    y = y0r;
-                }
+                y = posterior_update(cf, t, y, mu, eps, z);
                 store_state(T - t, y);
             }
         }
@@ -1202,7 +1223,7 @@ void guided_destroy(card_sampler* s) {
 // memory beyond LDS / registers (weights in registers or LDS, gamma rows prefetched a step ahead), so it does not move
 // with the shader clock or with HBM speed; it would move with the MFMA issue rate of another chip generation.
 // Measured on MI355X, tools/bench_small.py (profiles/r03_small_batch_ab.jsonl):
-constexpr double kRho16 = 1.65;    // 16-chain tiles: timestep of two tiles sharing a CU (5.3 us) / of one tile alone (3.2 us)
+constexpr double kRho16 = 1.68;    // 16-chain tiles: timestep of two tiles sharing a CU (5.27 us) / of one tile alone with every CU busy (3.14 us)
 constexpr double kRho32 = 1.717;   // 32-chain tiles: 9.1 us / 5.3 us
 constexpr int kCoopMaxRoundsX2 = 7;  // cooperative form up to 3.5 rounds of 2 tiles per CU (9.0 ms per round against 18.0 / 33.8 ms
                                      // per 4 / 8 tiles per CU on the persistent kernel)

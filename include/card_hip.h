@@ -168,7 +168,7 @@ typedef struct card_run_args {
     const float* y_init;    /* device (N, y_dim) state at timestep t_hi+... : y_t fed to the first step.
                                NULL = start of a loop: y_T = noise draw 0 + y_T_mean (diffusion_utils.py:109-110);
                                requires t_hi == T-1 */
-    const float* coef;      /* device (T, 8) from card_make_coef_table */
+    const float* coef;      /* device (T, 8) from card_make_coef_table, 16-byte aligned */
     const float* noise;     /* device (n_draws, N, y_dim) injected N(0,1) draws in consumption order, or NULL
                                for the in-kernel Philox4x32-10 generator.  n_draws = (y_init ? 0 : 1) +
                                number of processed timesteps with t >= 1 */
