@@ -127,6 +127,7 @@ void card_tune_from_env(CardTune* t) {
     t->coop_no2 = env_has("CARD_AMD_COOP", "no2");
     t->stream_off = env_has("CARD_AMD_STREAM", "off", '0');
     t->stream_big = env_has("CARD_AMD_STREAM", "big");
+    t->stream_nosplit = env_has("CARD_AMD_STREAM", "nosplit");
     t->cls_off = env_has("CARD_AMD_CLSCOOP", "off", '0');
     t->cls_noslice = env_has("CARD_AMD_CLSCOOP", "noslice");
     t->wide_gemmhead = env_has("CARD_AMD_WIDE", "gemmhead");

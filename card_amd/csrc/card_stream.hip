@@ -70,11 +70,24 @@ namespace {
 // kWaves = 8: the full-chip form (two waves per SIMD).  kWaves = 4: the same kernel with one wave per SIMD and half as many
 // chains per workgroup, for batches of at most num_cu * 64 chains (the reference's per-minibatch calls): the 8-wave form
 // would leave half of the CUs without a workgroup there.
-template <int H, int KS1, int kWaves>
+// SPLIT = 4 (round 3): a tile-timestep is a dependent chain of 2 112 MFMAs for the wave that owns it (43.6 us) however
+// small the batch, so below num_cu * 64 chains SIMDs idle while the others run at full length.  Here four waves (on four
+// different SIMDs) share one 16-chain tile -- one tile per workgroup with kWaves = 4, two with kWaves = 8 (two waves per
+// SIMD: the tiles cover each other's waits; a tile over two of four waves was built too and lost to this form, 24.2 vs
+// 20.7 ms per 1000 timesteps at 8 192 chains): wave `part` computes output features
+// [part * H / SPLIT, (part + 1) * H / SPLIT) of every layer from its share of each slab's A fragments, and after each
+// epilogue the waves trade their activations through LDS (same lane to same lane: the register layout is identical in
+// all of them), so every wave again holds the whole 256-feature vector as B operands; lin4 and the update run redundantly
+// in every wave of the tile.  Per output element the FMA chain over k is unchanged: bit-identical to SPLIT = 1.
+template <int H, int KS1, int kWaves, int SPLIT = 1>
 __global__ __launch_bounds__(kWaves * 64, kWaves == 8 ? 2 : 1) void card_sample_stream_kernel(const StreamParams p) {
     using G = Geo<H>;
     constexpr int kThreads = kWaves * 64;
     constexpr int NT = G::NT, NQ = G::NQ, NSH = G::NSH, SLAB = G::SLAB;
+    static_assert(SPLIT == 1 || SPLIT == 4, "a tile belongs to one wave or is shared by four");
+    constexpr int NTW = NT / SPLIT;                       // output tiles (of 16 features) this wave computes
+    constexpr int NQW = NQ / SPLIT;                       // its ds_read_b128 per k-step
+    constexpr int TPW = kWaves / SPLIT;                   // tiles per workgroup
     constexpr int NS1 = (KS1 + kSlabKs - 1) / kSlabKs;
     constexpr int NS = NS1 + 2 * NSH;                     // slabs per timestep
     constexpr int NST = SLAB / (kThreads * 4);            // b128 words of a slab each thread moves global -> ring
@@ -87,6 +100,8 @@ __global__ __launch_bounds__(kWaves * 64, kWaves == 8 ? 2 : 1) void card_sample_
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, n = lane & 15;
+    const int part = wave % SPLIT, tl = wave / SPLIT;    // which share of which of the workgroup's tiles
+    float* const xb = gbuf + 2 * G::GROW + (tl * NT * 64 + lane) * 4;   // SPLIT > 1: this tile's activation exchange, + j * 256
 
     // slabs come through a buffer resource with a scalar offset: no per-lane 64-bit addresses to keep (or spill)
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wimg), 0, NS * SLAB * 4, 0x00020000);
@@ -118,15 +133,22 @@ __global__ __launch_bounds__(kWaves * 64, kWaves == 8 ? 2 : 1) void card_sample_
     int gcur = 0;     // gamma buffer of the current step
     // A fragments of the k-step about to run, always one k-step ahead of the MFMAs (also across slab, layer and
     // timestep boundaries: the slab sequence is one endless stream)
-    f32x4 afrag[2][NQ];
+    // SPLIT > 1: a k-step of a wave is 8 / 4 MFMAs (256 / 128 cycles), shorter than an LDS read takes to return to a lone
+    // wave, so the fragments run THREE k-steps ahead there (a ring of four sets; one ahead measured 16.5 instead of ~11 us
+    // per timestep with a tile over four waves)
+    constexpr int NA = SPLIT > 1 ? 4 : 2, DA = NA - 1;
+    static_assert(SPLIT == 1 || KS1 % 4 == 0, "split forms: layer-1 slabs of a multiple of four k-steps (the host runs KS1 = 2 models on the KS1 = 4 kernel)");
+    f32x4 afrag[NA][NQW];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) afrag[0][q] = lds4(wbuf + lane * 4 + q * 256);
+    for (int d = 0; d < DA; ++d)
+#pragma unroll
+        for (int q = 0; q < NQW; ++q) afrag[d][q] = lds4(wbuf + lane * 4 + (d * NQ + part * NQW + q) * 256);
 
     const float* const bl = tabs + 4 * g;
     const float* const w4l = tabs + 3 * H + 4 * g;
     const float b4 = tabs[4 * H];
     const long long n_rows = p.n_end - p.n_begin;
-    const long long n_groups = (n_rows + kWaves * kTile - 1) / (kWaves * kTile);
+    const long long n_groups = (n_rows + TPW * kTile - 1) / (TPW * kTile);
     const int iters = (int)((n_groups + gridDim.x - 1) / gridDim.x);   // same for every workgroup: barriers inside
     const int T = p.T;
     const int draw0 = p.y_init ? (T - p.t_hi) : 0;
@@ -134,7 +156,7 @@ __global__ __launch_bounds__(kWaves * 64, kWaves == 8 ? 2 : 1) void card_sample_
 
     for (int it = 0; it < iters; ++it) {
         const long long group = (long long)it * gridDim.x + blockIdx.x;
-        const long long row = p.n_begin + (group * kWaves + wave) * kTile + n;
+        const long long row = p.n_begin + (group * TPW + tl) * kTile + n;
         const bool valid = row < p.n_end;                      // workgroups past the end run on clamped chains
         const long long rc = valid ? row : p.n_end - 1;
         const long long rr = p.n_z > 1 ? rc / p.n_z : rc;
@@ -168,7 +190,7 @@ __global__ __launch_bounds__(kWaves * 64, kWaves == 8 ? 2 : 1) void card_sample_
             if (p.out_mode == CARD_OUT_ALL) slot = s - slot_base;
             else if (p.out_mode == CARD_OUT_SELECT) slot = p.state_slot[s];
             else return;
-            if (slot >= 0 && valid && g == 0) p.out[slot * p.N + row] = v;
+            if (slot >= 0 && valid && g == 0 && part == 0) p.out[slot * p.N + row] = v;
         };
         float y;
         if (p.y_init) {
@@ -186,11 +208,11 @@ __global__ __launch_bounds__(kWaves * 64, kWaves == 8 ? 2 : 1) void card_sample_
             const float z = (t >= 1 && !p.eps_only) ? draw(T - t) : 0.0f;
             const float* const gl = gbuf + gcur * G::GROW + 4 * g;
 
-            f32x4 acc[NT];
+            f32x4 acc[NTW];
             float h[4 * NT];
             auto load_bias = [&](int layer) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[j] = lds4(bl + layer * H + 16 * j);
+                for (int j = 0; j < NTW; ++j) acc[j] = lds4(bl + layer * H + 16 * (part * NTW + j));
             };
             // One slab = NKS k-steps: acc[j] += A(slab)[j][ks] * b[OFF + ks].  Ring protocol (3 buffers, ONE barrier per
             // slab, placed mid-slab where every wave has MFMA work on both sides of it):
@@ -200,36 +222,59 @@ __global__ __launch_bounds__(kWaves * 64, kWaves == 8 ? 2 : 1) void card_sample_
             //   end:   the last k-step prefetches the first A fragments of slab q+1 -- no bubble at the boundary
             auto slab = [&](auto nks_tag, auto off_tag, const auto& b) {
                 constexpr int NKS = decltype(nks_tag)::value, OFF = decltype(off_tag)::value;
-                static_assert(NKS % 2 == 0, "fragment double buffer parity");
+                static_assert(NKS % NA == 0, "the fragment ring restarts at every slab");
+                // the barrier: mid-slab, and before the first fragment of the NEXT slab is asked for (k-step NKS - DA)
+                constexpr int BAR = NKS / 2 < NKS - DA ? NKS / 2 : NKS - DA;
                 const int nb = cur == G::RING - 1 ? 0 : cur + 1;
-                const float* wl = wbuf + cur * SLAB + lane * 4;
-                const float* wn = wbuf + nb * SLAB + lane * 4;
+                const float* wl = wbuf + cur * SLAB + lane * 4 + part * NQW * 256;
+                const float* wn = wbuf + nb * SLAB + lane * 4 + part * NQW * 256;
                 stage_to_ring(nb);
                 slab_fetch(nxt);
                 nxt = nxt + 1 == NS ? 0 : nxt + 1;
 #pragma unroll
                 for (int s = 0; s < NKS; ++s) {
-                    if (s == NKS / 2) __syncthreads();
+                    if (s == BAR) __syncthreads();
                     asm volatile("" ::: "memory");       // keep the scheduler from hoisting a whole slab's LDS reads
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q)
-                        afrag[(s + 1) & 1][q] = lds4(s + 1 < NKS ? wl + ((s + 1) * NQ + q) * 256 : wn + q * 256);
+                    for (int q = 0; q < NQW; ++q)
+                        afrag[(s + DA) % NA][q] = lds4(s + DA < NKS ? wl + ((s + DA) * NQ + q) * 256 : wn + ((s + DA - NKS) * NQ + q) * 256);
                     asm volatile("" ::: "memory");
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
+                    for (int q = 0; q < NQW; ++q) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            acc[4 * q + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[s & 1][q][e], b[OFF + s], acc[4 * q + e], 0, 0, 0);
+                            acc[4 * q + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[s % NA][q][e], b[OFF + s], acc[4 * q + e], 0, 0, 0);
                     }
                 }
                 cur = nb;
             };
             auto epilogue = [&](int layer) {
+                if constexpr (SPLIT == 1) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const f32x4 gm = lds4(gl + layer * H + 16 * j);
+                    for (int j = 0; j < NT; ++j) {
+                        const f32x4 gm = lds4(gl + layer * H + 16 * j);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) h[4 * j + r] = softplus_l2(acc[j][r] * gm[r]);
+                        for (int r = 0; r < 4; ++r) h[4 * j + r] = softplus_l2(acc[j][r] * gm[r]);
+                    }
+                } else {
+                    // this wave's share to the tile's exchange block, then the whole vector back in register order (own
+                    // share included: static register indices).  The block is rewritten one layer later, behind at least
+                    // one slab barrier that every wave passes only after its reads below have returned (LDS returns in order).
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) {
+                        const f32x4 gm = lds4(gl + layer * H + 16 * (part * NTW + j));
+                        f32x4 v;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = softplus_l2(acc[j][r] * gm[r]);
+                        *reinterpret_cast<f32x4*>(xb + (part * NTW + j) * 256) = v;
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const f32x4 v = lds4(xb + j * 256);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) h[4 * j + r] = v[r];
+                    }
                 }
             };
 
@@ -260,19 +305,19 @@ __global__ __launch_bounds__(kWaves * 64, kWaves == 8 ? 2 : 1) void card_sample_
                 epilogue(layer);
             }
             // ---- lin4 (:51): per-lane partial over its 64 features, then across the four lane groups
-            float part = 0.0f;
+            float dot = 0.0f;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const f32x4 w = lds4(w4l + 16 * j);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) part = fmaf(h[4 * j + r], w[r], part);
+                for (int r = 0; r < 4; ++r) dot = fmaf(h[4 * j + r], w[r], dot);
             }
-            part += __shfl_xor(part, 16, 64);
-            part += __shfl_xor(part, 32, 64);
-            const float eps = part + b4;
+            dot += __shfl_xor(dot, 16, 64);
+            dot += __shfl_xor(dot, 32, 64);
+            const float eps = dot + b4;
 
             if (p.eps_only) {
-                if (valid && g == 0) p.out[row] = eps;
+                if (valid && g == 0 && part == 0) p.out[row] = eps;
             } else {
                 // posterior update, regression/diffusion_utils.py:83-89 (t >= 1) / :101-103 (t == 0)
                 const float* c = p.coef + (long long)t * CARD_COEF_COLS;
@@ -289,7 +334,7 @@ __global__ __launch_bounds__(kWaves * 64, kWaves == 8 ? 2 : 1) void card_sample_
             if (tid < G::GROW / 4) *reinterpret_cast<f32x4*>(gbuf + (gcur ^ 1) * G::GROW + tid * 4) = gn;
             gcur ^= 1;
         }
-        if (p.out_mode == CARD_OUT_LAST && !p.eps_only && valid && g == 0) p.out[row] = y;
+        if (p.out_mode == CARD_OUT_LAST && !p.eps_only && valid && g == 0 && part == 0) p.out[row] = y;
     }
 }
 
@@ -352,21 +397,26 @@ int stream_ks1_for(int d_in) {
     return 0;
 }
 
-template <int W>
+template <int W, int S>
 stream_kernel_t stream_kernel_pick(int ks1) {
+    // (the packed image zero-fills a layer-1 slab beyond d_in and the kernel feeds zeros for columns beyond d_in, so a
+    // model packed for two k-steps also runs, with the same results, on the kernel that walks four)
+    if (S > 1 && ks1 == 2) ks1 = 4;
     switch (ks1) {
-        case 2: return card_sample_stream_kernel<256, 2, W>;
-        case 4: return card_sample_stream_kernel<256, 4, W>;
-        case 8: return card_sample_stream_kernel<256, 8, W>;
-        case 16: return card_sample_stream_kernel<256, 16, W>;
-        case 24: return card_sample_stream_kernel<256, 24, W>;
+        case 2: if constexpr (S == 1) return card_sample_stream_kernel<256, 2, W, S>; else return nullptr;
+        case 4: return card_sample_stream_kernel<256, 4, W, S>;
+        case 8: return card_sample_stream_kernel<256, 8, W, S>;
+        case 16: return card_sample_stream_kernel<256, 16, W, S>;
+        case 24: return card_sample_stream_kernel<256, 24, W, S>;
         default: return nullptr;
     }
 }
 
-stream_kernel_t stream_kernel_for(int H, int ks1, int waves) {
+// waves per workgroup (8 | 4) and waves per tile (1 | 4)
+stream_kernel_t stream_kernel_for(int H, int ks1, int waves, int split = 1) {
     if (H != 256) return nullptr;
-    return waves == kWavesFull ? stream_kernel_pick<kWavesFull>(ks1) : stream_kernel_pick<kWavesSmall>(ks1);
+    if (waves == kWavesFull) return split == 4 ? stream_kernel_pick<kWavesFull, 4>(ks1) : stream_kernel_pick<kWavesFull, 1>(ks1);
+    return split == 4 ? stream_kernel_pick<kWavesSmall, 4>(ks1) : stream_kernel_pick<kWavesSmall, 1>(ks1);
 }
 
 }  // namespace
@@ -389,7 +439,12 @@ int stream_create(card_sampler* s, const card_model_desc* d, hipStream_t stream)
     HIP_TRY(hipMalloc(&s->w1s, (size_t)(4 * H + 4) * sizeof(float)));
     HIP_TRY(hipMalloc(&s->gtab, (size_t)d->n_embed * 3 * H * sizeof(float)));
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
-    HIP_TRY(hipFuncSetAttribute((const void*)stream_kernel_for(H, ks1, kWavesSmall), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
+    // (+ the activation exchange of the forms that split a tile over 2 / 4 waves: 16 KB per tile of the workgroup)
+    for (int split : {1, 4})
+        HIP_TRY(hipFuncSetAttribute((const void*)stream_kernel_for(H, ks1, kWavesSmall, split), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(s->lds_bytes + (split > 1 ? (kWavesSmall / split) * (H / 16) * 256 * sizeof(float) : 0))));
+    HIP_TRY(hipFuncSetAttribute((const void*)stream_kernel_for(H, ks1, kWavesFull, 4), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(s->lds_bytes + (kWavesFull / 4) * (H / 16) * 256 * sizeof(float))));
     stream_pack_kernel<<<512, 256, 0, stream>>>(d->W[0], d->W[1], d->W[2], H, d_in, ns1, s->wpk);
     stream_tabs_kernel<<<1, 256, 0, stream>>>(d->b[0], d->b[1], d->b[2], d->W4, d->b4, H, s->w1s);
     stream_gamma_kernel<<<512, 256, 0, stream>>>(d->gamma[0], d->gamma[1], d->gamma[2], d->n_embed, H, s->gtab);
@@ -415,22 +470,34 @@ int stream_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     // Small batches (at most num_cu * 4 waves * 16 chains = 16 384 on 256 CUs): four waves per workgroup, one per SIMD,
     // so every SIMD of the chip gets a tile; the 8-wave form would run them on half of the CUs.  CARD_AMD_STREAM=big
     // keeps the 8-wave form (A/B); results are identical (same per-chain arithmetic).
-    const bool small = !s->tune.stream_big && p.N <= (long long)s->num_cu * kWavesSmall * kTile;
-    const int waves = small ? kWavesSmall : kWavesFull;
+    // Forms by batch size (256 CUs): above num_cu * 64 chains eight waves per workgroup, a tile each (two waves per SIMD);
+    // up to num_cu * 64 = 16 384 four waves, a tile each, so that every CU gets a workgroup; up to num_cu * 32 = 8 192 eight
+    // waves with every tile shared by four of them (two tiles per CU, two waves per SIMD: a tile-timestep is a quarter as
+    // long and the two tiles cover each other's waits); up to num_cu * 16 = 4 096 four waves sharing one tile per CU.
+    // CARD_AMD_STREAM=big: always the first form; nosplit: never a shared tile (tests, A/B; results are identical).
+    const long long per_cu = (p.N + s->num_cu - 1) / s->num_cu;
+    int waves = kWavesFull, split = 1;
+    if (!s->tune.stream_big && per_cu <= kWavesSmall * kTile) {
+        waves = kWavesSmall;
+        if (!s->tune.stream_nosplit && per_cu <= kTile) split = 4;
+        else if (!s->tune.stream_nosplit && per_cu <= 2 * kTile) { waves = kWavesFull; split = 4; }
+    }
     if (r.plan)      // layer 1 on MFMA every step with K padded to 4 * ks1 columns, two H x H layers, lin4 (VALU)
-        r.plan->executed = 2.0 * s->hidden * (4 * s->k1 + 2 * s->hidden) + 2.0 * s->hidden;
-    stream_kernel_t kern = small ? stream_kernel_for(s->hidden, s->k1, kWavesSmall) : reinterpret_cast<stream_kernel_t>(s->kernel);
+        r.plan->executed = 2.0 * s->hidden * (4 * ((split > 1 && s->k1 == 2) ? 4 : s->k1) + 2 * s->hidden) + 2.0 * s->hidden;
+    stream_kernel_t kern = stream_kernel_for(s->hidden, s->k1, waves, split);
+    const size_t lds_bytes = s->lds_bytes + (split > 1 ? (size_t)(waves / split) * (s->hidden / 16) * 256 * sizeof(float) : 0);
     // launches of at most num_cu workgroups x kGroupsPerWg groups x 128 chains: every workgroup walks the same
     // number of groups (the kernel's barriers need that) and one launch stays well under a second
-    const long long group = waves * kTile;
+    const long long group = waves / split * kTile;
     const long long chunk = (long long)s->num_cu * kGroupsPerWg * group;
     for (long long b = 0; b < p.N; b += chunk) {
         p.n_begin = b;
         p.n_end = b + chunk < p.N ? b + chunk : p.N;
         const long long groups = (p.n_end - p.n_begin + group - 1) / group;
         const long long grid = groups < s->num_cu ? groups : s->num_cu;
-        CARD_LAUNCH(r, small ? "card_sample_stream_kernel (4 waves)" : "card_sample_stream_kernel", true,
-                    kern<<<dim3((unsigned)grid), dim3(waves * 64), s->lds_bytes, stream>>>(p));
+        CARD_LAUNCH(r, split == 4 ? (waves == kWavesFull ? "card_sample_stream_kernel (8 waves, tile over 4 waves)" : "card_sample_stream_kernel (4 waves, tile over 4 waves)")
+                       : waves == kWavesSmall ? "card_sample_stream_kernel (4 waves)" : "card_sample_stream_kernel", true,
+                    kern<<<dim3((unsigned)grid), dim3(waves * 64), lds_bytes, stream>>>(p));
     }
     return CARD_OK;
 }

@@ -136,3 +136,36 @@ def test_four_wave_and_eight_wave_forms_agree_bit_for_bit(N, monkeypatch):
         s = Sampler.from_state_dict(sd, device=DEV)
         outs.append(s.run(cuda(x), cuda(y0), cuda(mu), coef, T, seed=3, out_mode=_lib.OUT_ALL))
     assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0]).all()
+
+
+@pytest.mark.parametrize("N", [16, 700, 4096, 4097, 8192])
+def test_tile_split_over_waves_agrees_bit_for_bit(N, monkeypatch, wave_form):
+    """Up to num_cu * 32 chains a 16-chain tile is shared by 4 waves (each computes a share of every
+    layer's output features and the activations are traded through LDS, card_stream.hip SPLIT): every output element is the
+    same FMA chain over k, so CARD_AMD_STREAM=nosplit (one wave per tile) gives the same bits -- RNG mode, every state,
+    in-kernel row tiling, eps_theta -- and the plan names the form."""
+    if wave_form != "small4":
+        pytest.skip("the split forms belong to the four-wave form")
+    T, n_z = 9, 1
+    rows = N
+    sd, x, y0, mu, _, alphas, omabs = _case(13, T, rows, 40 + N % 7)
+    coef = cuda(make_coef_table(alphas, omabs))
+    outs, eps = [], []
+    for env in ("", "nosplit"):
+        monkeypatch.setenv("CARD_AMD_STREAM", env)
+        s = Sampler.from_state_dict(sd, device=DEV)
+        kw = dict(seed=3, elem_offset=17, out_mode=_lib.OUT_ALL)
+        outs.append(s.run(cuda(x), cuda(y0), cuda(mu), coef, T, **kw))
+        eps.append(s.eps_theta(cuda(x), cuda(y0), cuda(y0), 4))
+        form = s.run(cuda(x), cuda(y0), cuda(mu), coef, T, plan=True, **kw)["kernel"]
+        want = "(4 waves)" if env or N > 8192 else ("(4 waves, tile over 4 waves)" if N <= 4096 else "(8 waves, tile over 4 waves)")      # 256 CUs
+        assert want in form, form
+    assert torch.equal(outs[0], outs[1]) and torch.equal(eps[0], eps[1]) and torch.isfinite(outs[0]).all()
+    if N >= 700:        # rows tiled in-kernel: 7 chains per row, ragged against the 16-chain tiles
+        r = N // 7
+        monkeypatch.setenv("CARD_AMD_STREAM", "")
+        s = Sampler.from_state_dict(sd, device=DEV)
+        a = s.run(cuda(x[:r]), cuda(y0[:r]), cuda(mu[:r]), coef, T, seed=5, n_z=7)
+        monkeypatch.setenv("CARD_AMD_STREAM", "nosplit")
+        s1 = Sampler.from_state_dict(sd, device=DEV)
+        assert torch.equal(a, s1.run(cuda(x[:r]), cuda(y0[:r]), cuda(mu[:r]), coef, T, seed=5, n_z=7))
