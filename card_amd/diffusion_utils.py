@@ -9,6 +9,7 @@ Everything here runs on the GPU through libcard_hip.so.  No fallback.
 """
 import math
 import threading
+import weakref
 
 import numpy as np
 import torch
@@ -218,13 +219,13 @@ def _take_ahead(c, y, t, seed, elem_offset):
     la = c.ahead
     if la is None:
         return None
-    if (y is c.prev_out and y._version == c.prev_ver and t == la.t_first - la.next and seed == la.seed
+    if (c.prev_out is not None and y is c.prev_out() and y._version == c.prev_ver and t == la.t_first - la.next and seed == la.seed
             and elem_offset == la.elem_offset):
         out = la.buf[la.next]
         la.next += 1
         if la.next == la.k:
             c.ahead = None
-        c.prev_out, c.prev_ver = out, out._version
+        c.prev_out, c.prev_ver = weakref.ref(out), out._version      # weak: the context pins none of the states it handed out
         return out
     c.ahead = None
     return None
@@ -240,7 +241,7 @@ def _step_run(c, a, y, t, noise, seed, elem_offset, t_min=None):
         raise CardError(f"y: expected shape ({c.N}, {s.y_dim}), got {tuple(y.shape)}")
     # how many timesteps this launch runs: 1, or -- when the call continues the previous one -- twice as many as that one
     k = 1
-    if (t_min is not None and noise is None and LOOKAHEAD_MAX_STEPS > 1 and y_in is c.prev_out
+    if (t_min is not None and noise is None and LOOKAHEAD_MAX_STEPS > 1 and c.prev_out is not None and y_in is c.prev_out()
             and y_in._version == c.prev_ver and t == c.last_t - 1):
         k = min(2 * max(c.prev_k, 1), LOOKAHEAD_MAX_STEPS, t - t_min + 1,
                 max(1, LOOKAHEAD_MAX_BYTES // (4 * c.N * s.y_dim)))
@@ -262,7 +263,7 @@ def _step_run(c, a, y, t, noise, seed, elem_offset, t_min=None):
         out = torch.empty_like(y)
         a.t_hi = a.t_lo = t
         a.y_init, a.out, a.noise = y.data_ptr(), out.data_ptr(), (nz.data_ptr() if nz is not None else None)
-    c.prev_out, c.prev_ver, c.prev_k = out, out._version, k
+    c.prev_out, c.prev_ver, c.prev_k = weakref.ref(out), out._version, k
     a.seed, a.elem_offset = seed & (2 ** 64 - 1), int(elem_offset)
     if torch.cuda.current_device() == s.device.index:
         rc = c.fn(s._h, a, _stream(s.device))
