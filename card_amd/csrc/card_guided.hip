@@ -839,6 +839,13 @@ __device__ __forceinline__ void epilogue16(f32x4 (&acc)[2], const f32x4 (&gm)[2]
     __builtin_amdgcn_s_setprio(kPrioMfma);
 }
 
+#ifdef CARD_COOP16_PROFILE
+__device__ long long g_c16_prof[64];
+#define PROF16(i) do { pts[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PROF16(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(const RunParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -1025,6 +1032,10 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
     };
 
     for (int it = 0; it < n_iter; ++it) {
+#ifdef CARD_COOP16_PROFILE
+        long long pts[8];
+#endif
+        PROF16(0);
         const bool on = active && it < quota;
         const int t = th - it;
         const bool more = on && it + 1 < quota;
@@ -1045,13 +1056,17 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
             epilogue16(acc, gm1);
             publish(acc, 0);
         }
+        PROF16(1);
         __syncthreads();
+        PROF16(2);
         if (on) {
             z = t >= 1 && !p.eps_only ? draw(T - t) : 0.0f;
             hidden(A2, 0, 1, gl, bias2, acc);
             publish(acc, 1);
         }
+        PROF16(3);
         __syncthreads();
+        PROF16(4);
         if (on) {
             hidden(A3, 1, 2, gl, bias3, acc);
             if (more && htid < kGammaRow / 4) *reinterpret_cast<f32x4*>(gsl + (gcur ^ 1) * kGammaRow + htid * 4) = gn;
@@ -1080,7 +1095,9 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
             }
             if (g == 2) red[w * kT16 + n] = part;
         }
+        PROF16(5);
         __syncthreads();
+        PROF16(6);
         if (on) {
             const float eps = (((red[n] + red[kT16 + n]) + red[2 * kT16 + n]) + red[3 * kT16 + n]) + b4;
             gcur ^= more ? 1 : 0;
@@ -1091,6 +1108,14 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
                 store_state(T - t, y);
             }
         }
+#ifdef CARD_COOP16_PROFILE
+        PROF16(7);
+        asm volatile("" : "+v"(y));
+        if (blockIdx.x == 0 && lane == 0 && half == 0) {
+            for (int i = 0; i < 7; ++i) g_c16_prof[w * 8 + i] += pts[i + 1] - pts[i];
+            g_c16_prof[w * 8 + 7] += 1;
+        }
+#endif
     }
     if (valid && g == 0 && w == 0 && !p.eps_only) {
         if (!last_seg) p.ybuf[row] = y;
@@ -1343,3 +1368,12 @@ int guided_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     }
     return CARD_OK;
 }
+
+#ifdef CARD_COOP16_PROFILE
+// profile build only (tools/prof_c16_phases.py): cycles per phase of workgroup 0's first half, [wave][phase], [wave][7] = timesteps
+extern "C" CARD_API int card_debug_c16_prof(long long* host64, int reset) {
+    if (host64) HIP_TRY(hipMemcpyFromSymbol(host64, HIP_SYMBOL(g_c16_prof), sizeof(long long) * 64));
+    if (reset) { long long z[64] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_c16_prof), z, sizeof(z))); }
+    return CARD_OK;
+}
+#endif
