@@ -899,9 +899,14 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
     const float* const tb = tab + 32 * w + 4 * g;                                  // bias: + layer * kH + 16 mb
     const float* const w4l = tab + (kOffW4 - kOffB) + 32 * w + 4 * g;              // + 16 mb
     const float b4 = tab[kOffB4 - kOffB];
-    float a10[2];
+    // column 0 of W1 for this lane's eight features 32w + 16mb + 4g + r: layer 1 = c1 + W1[:, 0] * y_t is one fmaf per
+    // accumulator register here.  The other kernels issue it as a K = 2 MFMA whose only non-zero product is the same
+    // (w, y): the MFMA is a sequential fmaf chain over k (tools/ubench/mfma_order.hip), fmaf(0, 0, x) = x, so the bits are
+    // the same (up to the sign of a zero, which exp2 does not see) -- and a lone wave does not wait out an MFMA's latency
+    // between the update and the first epilogue
+    f32x4 w1c[2];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) a10[mb] = g == 0 ? tab[(kOffW1 - kOffB) + 32 * w + 16 * mb + n] : 0.0f;
+    for (int mb = 0; mb < 2; ++mb) w1c[mb] = lds4(tab + (kOffW1 - kOffB) + 32 * w + 16 * mb + 4 * g);
     // loop-invariant LDS tables this lane needs every timestep, held in registers (LDS reads are not hoisted over the
     // loop's barriers by the compiler, and a read placed next to its use costs a full LDS latency in the dependent chain)
     f32x4 w4r[2], bias2[2], bias3[2];
@@ -997,6 +1002,11 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
         }
     }
     int gcur = 0;
+    // layer 1's gamma values of the NEXT timestep are read right behind the barrier that publishes their row (the third
+    // of a timestep), ahead of the update chain, instead of at the head of the next timestep
+    f32x4 gm1[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) gm1[mb] = lds4(gsl + 4 * g + 32 * w + 16 * mb);
 
     auto publish = [&](const f32x4 (&a)[2], int buf) {
 #pragma unroll
@@ -1047,12 +1057,11 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
         if (on) {
             if (!p.eps_only) cf = load_coef(p.coef, t);
             if (more && htid < kGammaRow / 4) gn = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(t - 1) * kGammaRow + htid * 4);
-            f32x4 gm1[2];
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) gm1[mb] = lds4(gl + 32 * w + 16 * mb);
             if (t >= 1 && !p.eps_only) zfill(T - t);
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a10[mb], g == 0 ? y : 0.0f, c1[mb], 0, 0, 0);
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mb][r] = fmaf(w1c[mb][r], y, c1[mb][r]);
             epilogue16(acc, gm1);
             publish(acc, 0);
         }
@@ -1099,8 +1108,10 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
         __syncthreads();
         PROF16(6);
         if (on) {
-            const float eps = (((red[n] + red[kT16 + n]) + red[2 * kT16 + n]) + red[3 * kT16 + n]) + b4;
             gcur ^= more ? 1 : 0;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) gm1[mb] = lds4(gsl + gcur * kGammaRow + 4 * g + 32 * w + 16 * mb);
+            const float eps = (((red[n] + red[kT16 + n]) + red[2 * kT16 + n]) + red[3 * kT16 + n]) + b4;
             if (p.eps_only) {
                 if (valid && g == 0 && w == 0) p.out[row] = eps;
             } else {
