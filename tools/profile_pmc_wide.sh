@@ -13,7 +13,7 @@ run_pass() {
       > "$R/$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$R/$OUT/$name.log"; exit 1; }
   echo "pass $name ok"
 }
-if [ "${2:-all}" = "tcc" ]; then          # fabric traffic only (A/B of CARD_AMD_WIDE_ORDER, taken from the environment)
+if [ "${2:-all}" = "tcc" ]; then          # fabric traffic only
   run_pass tcc_fetch FETCH_SIZE GRBM_GUI_ACTIVE && run_pass tcc_write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
   exit $?
 fi
