@@ -127,3 +127,17 @@ def test_two_rank_bench_line_on_one_gpu_through_gloo():
     ratio = two["value"] / one["value"]
     print(f"1 rank {one['value']:.3e}, 2 ranks sharing the GPU {two['value']:.3e} sample-steps/s (ratio {ratio:.3f})")
     assert 0.80 <= ratio <= 1.15, ratio
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the one-GPU test box rehearses this path over gloo above)")
+def test_two_rank_bench_line_over_rccl():
+    """On a node with at least two GPUs: the driver's own N = 2 launch (torch.distributed.run, one rank per GPU, backend nccl =
+    RCCL over xGMI).  Weak scaling with no data-path collective: the whole-job value must come out near twice the one-rank
+    value."""
+    common = ["--workload", "toy", "--rows", "1049", "--nz", "1000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    one = _bench_child(["--gpus", "1"] + common)
+    two = _bench_child(["--gpus", "2"] + common, nproc=2)
+    assert two["n_gpus"] == 2 and two["config"]["backend"] == "nccl" and two["config"]["ranks_share_one_gpu"] is False
+    ratio = two["value"] / one["value"]
+    print(f"1 rank {one['value']:.3e}, 2 ranks on 2 GPUs {two['value']:.3e} sample-steps/s (ratio {ratio:.3f})")
+    assert 1.7 <= ratio <= 2.2, ratio
