@@ -68,6 +68,25 @@ __device__ __forceinline__ float softplus_l2(float xs) {
 
 __device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+// One row of the (T, 8) coefficient table, requested at the TOP of a timestep: asked for where it is used (after lin4) the
+// load sat in the dependent chain of every timestep with its full L2 latency -- twice, the second half of the row behind
+// the t >= 1 branch (ISA of round 2's kernels).
+struct CoefRow { float inv_sab, om_sab, somab, g0, g1, g2, sigma; };
+__device__ __forceinline__ CoefRow load_coef(const float* coef, int t) {
+    const float* c = coef + (long long)t * CARD_COEF_COLS;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(c);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(c + 4);
+    return {a[CARD_COEF_INV_SQRT_AB], a[CARD_COEF_ONE_M_SQRT_AB], a[CARD_COEF_SOMAB], a[CARD_COEF_G0],
+            b[CARD_COEF_G1 - 4], b[CARD_COEF_G2 - 4], b[CARD_COEF_SIGMA - 4]};
+}
+// posterior update, regression/diffusion_utils.py:83-89 (t >= 1) / :101-103 (t == 0), unfused fp32 in the reference's order
+__device__ __forceinline__ float posterior_update(const CoefRow& c, int t, float y, float mu, float eps, float z) {
+    const float y0r = c.inv_sab * ((y - c.om_sab * mu) - eps * c.somab);
+    if (t < 1) return y0r;
+    const float yh = (c.g0 * y0r + c.g1 * y) + c.g2 * mu;
+    return yh + c.sigma * z;
+}
+
 
 }  // namespace card
 

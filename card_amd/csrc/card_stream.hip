@@ -4,9 +4,10 @@
 // Same idea as card_guided.hip -- a wave owns its chains for all T timesteps, activations stay in registers in
 // the transposed (feature x chain) layout so that one layer's MFMA accumulators are the next layer's B operands
 // -- with two changes forced by the weight size:
-//   * weights are STREAMED: the three layers of a timestep are cut into 32 KB slabs (8 k-steps x all output
-//     features, already in A-fragment order in global memory, L2-resident) that every wave of the workgroup
-//     consumes in lockstep from a three-buffer LDS ring; slab i+2 is fetched global -> registers while slab i
+//   * weights are STREAMED (the eight-wave form for full batches; the four-wave forms for small batches take the same
+//     fragments straight from L2, see the kernel's comment): the three layers of a timestep are cut into 32 KB slabs
+//     (8 k-steps x all output features, already in A-fragment order in global memory, L2-resident) that every wave of
+//     the workgroup consumes in lockstep from a three-buffer LDS ring; slab i+2 is fetched global -> registers while slab i
 //     is computed, one barrier per slab placed MID-slab so that no wave drains its MFMA queue around it and
 //     A fragments are prefetched straight across slab boundaries.  The slab sequence is the same every
 //     timestep (layer 1 | layer 2 | layer 3), so the ring simply cycles.
@@ -67,24 +68,41 @@ struct StreamParams {
 
 namespace {
 
-// kWaves = 8: the full-chip form (two waves per SIMD).  kWaves = 4: the same kernel with one wave per SIMD and half as many
-// chains per workgroup, for batches of at most num_cu * 64 chains (the reference's per-minibatch calls): the 8-wave form
-// would leave half of the CUs without a workgroup there.
-// SPLIT = 4 (round 3): a tile-timestep is a dependent chain of 2 112 MFMAs for the wave that owns it (43.6 us) however
-// small the batch, so below num_cu * 64 chains SIMDs idle while the others run at full length.  Here four waves (on four
-// different SIMDs) share one 16-chain tile -- one tile per workgroup with kWaves = 4, two with kWaves = 8 (two waves per
-// SIMD: the tiles cover each other's waits; a tile over two of four waves was built too and lost to this form, 24.2 vs
-// 20.7 ms per 1000 timesteps at 8 192 chains): wave `part` computes output features
-// [part * H / SPLIT, (part + 1) * H / SPLIT) of every layer from its share of each slab's A fragments, and after each
-// epilogue the waves trade their activations through LDS (same lane to same lane: the register layout is identical in
-// all of them), so every wave again holds the whole 256-feature vector as B operands; lin4 and the update run redundantly
-// in every wave of the tile.  Per output element the FMA chain over k is unchanged: bit-identical to SPLIT = 1.
+// Two forms of one kernel:
+//  * kWaves = 8, a tile per wave (two waves per SIMD): the slab ring described above; every A fragment that enters the CU
+//    is used by eight waves.  Batches above num_cu * 64 chains.
+//  * kWaves = 4 (one wave per SIMD), DIRECT (round 3): no ring.  Below num_cu * 64 chains a workgroup holds at most four
+//    tiles, the ring buys little reuse and costs a lone wave a 32 KB store + a barrier per slab (timing-only builds:
+//    19 % of the loop, most of it the ds_write_b128 burst holding up the fragment reads queued behind it).  Every wave
+//    requests its own A fragments global -> registers, one buffer load of 1 KB per MFMA group, DD k-steps ahead of the
+//    MFMAs that consume them (L2-resident weights, 13-16 TB/s chip-wide: within what the L2s deliver); ring position P
+//    of a timestep lives in register set P % DD, timestep after timestep.
+//      SPLIT = 1: a tile per wave, four tiles per workgroup, one barrier per timestep (for the gamma row).
+//      SPLIT = 4: a tile-timestep is a dependent chain of 2 112 MFMAs for the wave that owns it however small the batch,
+//        so below num_cu * 32 chains four waves (on four SIMDs) share ONE 16-chain tile: wave `part` computes output
+//        features [64 part, 64 part + 64) of every layer from its quarter of the A fragments, and after each epilogue
+//        the waves trade their activations through LDS (same lane to same lane: the register layout is identical in all
+//        of them), so every wave again holds the whole 256-feature vector as B operands; lin4 and the update run
+//        redundantly in all four.  Per output element the FMA chain over k is unchanged: bit-identical to SPLIT = 1.
+//        The form stays within 256 registers, so two such workgroups fit a CU (num_cu * 16 < chains <= num_cu * 32) and
+//        cover each other's waits.
+//    (Round-3 forms this replaced, per 1000 timesteps at x_dim 13: the four-wave ring 43.9 ms at 16 384 chains -> 33.5;
+//    a shared tile on the four-wave ring 16.0 ms at 4 096 chains -> 9.9; two shared tiles on an eight-wave ring 20.7 ms at
+//    8 192 chains -> 17.5.)
+constexpr int kDirectDepth = 16;
+
 template <int H, int KS1, int kWaves, int SPLIT = 1>
-__global__ __launch_bounds__(kWaves * 64, kWaves == 8 ? 2 : 1) void card_sample_stream_kernel(const StreamParams p) {
+__global__ __launch_bounds__(kWaves * 64, (kWaves == 8 || SPLIT == 4) ? 2 : 1) void card_sample_stream_kernel(const StreamParams p) {
     using G = Geo<H>;
     constexpr int kThreads = kWaves * 64;
     constexpr int NT = G::NT, NQ = G::NQ, NSH = G::NSH, SLAB = G::SLAB;
-    static_assert(SPLIT == 1 || SPLIT == 4, "a tile belongs to one wave or is shared by four");
+    static_assert(SPLIT == 1 || (SPLIT == 4 && kWaves == 4), "a tile belongs to one wave or is shared by the four of a small workgroup");
+    constexpr bool DIRECT = kWaves == 4;
+    constexpr bool L1RES = SPLIT == 4 && KS1 <= 4;          // DIRECT: layer-1 fragments stay in registers (else they take their turn in the ring)
+    constexpr int DP1 = L1RES ? 0 : KS1;                    // ring positions of layer 1
+    constexpr int DPT = DP1 + 2 * G::KSH;                   // ring positions per timestep
+    constexpr int DD = SPLIT == 1 ? 4 : DPT % kDirectDepth == 0 ? kDirectDepth : kDirectDepth / 2;   // ring depth in k-steps (a k-step is 16 / SPLIT MFMAs)
+    static_assert(!DIRECT || DPT % DD == 0, "a k-step keeps its ring slot from timestep to timestep");
     constexpr int NTW = NT / SPLIT;                       // output tiles (of 16 features) this wave computes
     constexpr int NQW = NQ / SPLIT;                       // its ds_read_b128 per k-step
     constexpr int TPW = kWaves / SPLIT;                   // tiles per workgroup
@@ -94,55 +112,79 @@ __global__ __launch_bounds__(kWaves * 64, kWaves == 8 ? 2 : 1) void card_sample_
     static_assert(SLAB == NST * kThreads * 4, "a slab is a whole number of b128 per thread");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const wbuf = lds;
-    float* const tabs = lds + G::RING * SLAB;
+    float* const tabs = lds + (DIRECT ? 0 : G::RING * SLAB);
     float* const gbuf = tabs + G::TABS;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, n = lane & 15;
     const int part = wave % SPLIT, tl = wave / SPLIT;    // which share of which of the workgroup's tiles
-    float* const xb = gbuf + 2 * G::GROW + (tl * NT * 64 + lane) * 4;   // SPLIT > 1: this tile's activation exchange, + j * 256
+    float* const xb = gbuf + 2 * G::GROW + lane * 4;     // SPLIT = 4: the tile's two activation exchange blocks, + j * 256
+    int xpar = 0;                                        // ... and which of them the next epilogue uses
 
     // slabs come through a buffer resource with a scalar offset: no per-lane 64-bit addresses to keep (or spill)
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wimg), 0, NS * SLAB * 4, 0x00020000);
     const int voff = tid * 16;
     f32x4 stage[NST];         // the slab after the one being computed, on its way global -> registers -> ring
-    auto slab_fetch = [&](int slab) {
+    // words [i0, i1) of a slab: global -> registers, registers -> ring
+    auto slab_fetch = [&](int slab, int i0, int i1) {
         const int so = slab * (SLAB * 4);
 #pragma unroll
-        for (int i = 0; i < NST; ++i)
+        for (int i = i0; i < i1; ++i)
             stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, so + i * kThreads * 16, 0));
     };
-    auto stage_to_ring = [&](int buf) {
+    auto stage_to_ring = [&](int buf, int i0, int i1) {
         float* dst = wbuf + buf * SLAB + tid * 4;
 #pragma unroll
-        for (int i = 0; i < NST; ++i) *reinterpret_cast<f32x4*>(dst + i * kThreads * 4) = stage[i];
+        for (int i = i0; i < i1; ++i) *reinterpret_cast<f32x4*>(dst + i * kThreads * 4) = stage[i];
     };
 
     // prologue: tables, gamma row of the first step, slab 0 in ring buffer 0, slab 1 in flight
     for (int i = tid * 4; i < G::TABS; i += kThreads * 4)
         *reinterpret_cast<f32x4*>(tabs + i) = *reinterpret_cast<const f32x4*>(p.tabs + i);
     for (int i = tid; i < G::GROW; i += kThreads) gbuf[i] = p.gtab[(long long)p.t_hi * G::GROW + i];
-    slab_fetch(0);
-    stage_to_ring(0);
-    slab_fetch(1);
+    // DIRECT: this wave's A fragment of one k-step, 1 KB: lane l holds features 16 (4 part + e) + (l & 15), e = 0..3
+    f32x4 frag[DIRECT ? DD : 1][NQW], frag1[DIRECT && L1RES ? KS1 : 1];
+    const int voffd = lane * 16 + part * NQW * 1024;
+    auto frag_load = [&](int ks, int q) __attribute__((always_inline)) {      // k-step ks of the packed image (slabs of kSlabKs)
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            wrsrc, voffd, ((ks / kSlabKs) * SLAB + ((ks % kSlabKs) * NQ + q) * 256) * 4, 0));
+    };
+    // k-step (of the packed image) at ring position P
+    auto pos_ks = [](int P) __attribute__((always_inline)) { return P < DP1 ? P : NS1 * kSlabKs + (P - DP1); };
+    if constexpr (DIRECT) {
+        if constexpr (L1RES) {
+            static_assert(NQW == 1, "one b128 of A fragments per wave and k-step");
+#pragma unroll
+            for (int s = 0; s < KS1; ++s) frag1[s] = frag_load(s, 0);
+        }
+#pragma unroll
+        for (int P = 0; P < DD; ++P)
+#pragma unroll
+            for (int q = 0; q < NQW; ++q) frag[P][q] = frag_load(pos_ks(P), q);
+    } else {
+        slab_fetch(0, 0, NST);
+        stage_to_ring(0, 0, NST);
+        slab_fetch(1, 0, NST);
+    }
     __syncthreads();
 
     int cur = 0;      // ring buffer holding the slab being computed
     int nxt = 2;      // index (in the per-timestep cycle of NS slabs) of the slab fetched next
     int gcur = 0;     // gamma buffer of the current step
-    // A fragments of the k-step about to run, always one k-step ahead of the MFMAs (also across slab, layer and
-    // timestep boundaries: the slab sequence is one endless stream)
-    // SPLIT > 1: a k-step of a wave is 8 / 4 MFMAs (256 / 128 cycles), shorter than an LDS read takes to return to a lone
-    // wave, so the fragments run THREE k-steps ahead there (a ring of four sets; one ahead measured 16.5 instead of ~11 us
-    // per timestep with a tile over four waves)
-    constexpr int NA = SPLIT > 1 ? 4 : 2, DA = NA - 1;
-    static_assert(SPLIT == 1 || KS1 % 4 == 0, "split forms: layer-1 slabs of a multiple of four k-steps (the host runs KS1 = 2 models on the KS1 = 4 kernel)");
-    f32x4 afrag[NA][NQW];
+    // ring form: A fragments of the k-step about to run, always one k-step ahead of the MFMAs (also across slab, layer
+    // and timestep boundaries: the slab sequence is one endless stream)
+    constexpr int NA = 2, DA = NA - 1;
+    // (the one form the spread fill makes spill: two layer-1 slabs' worth of inputs)
+    constexpr bool SPREAD = KS1 != 8;
+    static_assert(!DIRECT || KS1 % 4 == 0, "direct forms: ring positions per timestep divisible by the ring depth (the host runs KS1 = 2 models on the KS1 = 4 kernel)");
+    f32x4 afrag[NA][NQ];
+    if constexpr (!DIRECT) {
 #pragma unroll
-    for (int d = 0; d < DA; ++d)
+        for (int d = 0; d < DA; ++d)
 #pragma unroll
-        for (int q = 0; q < NQW; ++q) afrag[d][q] = lds4(wbuf + lane * 4 + (d * NQ + part * NQW + q) * 256);
+            for (int q = 0; q < NQ; ++q) afrag[d][q] = lds4(wbuf + lane * 4 + (d * NQ + q) * 256);
+    }
 
     const float* const bl = tabs + 4 * g;
     const float* const w4l = tabs + 3 * H + 4 * g;
@@ -176,8 +218,7 @@ __global__ __launch_bounds__(kWaves * 64, kWaves == 8 ? 2 : 1) void card_sample_
 
         float zc[4];
         uint32_t zblock = 0xFFFFFFFFu;
-        auto draw = [&](int d) -> float {
-            if (p.noise) return p.noise[(long long)(d - draw0) * p.N + rc];
+        auto draw_rng = [&](int d) -> float {
             const uint32_t blk = (uint32_t)d >> 2;
             if (blk != zblock) {
                 philox_normal4(p.seed, elem, blk, zc);
@@ -185,10 +226,10 @@ __global__ __launch_bounds__(kWaves * 64, kWaves == 8 ? 2 : 1) void card_sample_
             }
             return pick4(zc, d & 3);
         };
-        auto store_state = [&](int s, float v) {
+        auto store_state = [&](int s, float v, int selected) {
             long long slot;
             if (p.out_mode == CARD_OUT_ALL) slot = s - slot_base;
-            else if (p.out_mode == CARD_OUT_SELECT) slot = p.state_slot[s];
+            else if (p.out_mode == CARD_OUT_SELECT) slot = selected;
             else return;
             if (slot >= 0 && valid && g == 0 && part == 0) p.out[slot * p.N + row] = v;
         };
@@ -196,16 +237,30 @@ __global__ __launch_bounds__(kWaves * 64, kWaves == 8 ? 2 : 1) void card_sample_
         if (p.y_init) {
             y = p.y_init[rc];
         } else {
-            y = draw(0) + mu;                                  // regression/diffusion_utils.py:109-110
-            store_state(0, y);
+            y = (p.noise ? p.noise[rc] : draw_rng(0)) + mu;    // regression/diffusion_utils.py:109-110
+            store_state(0, y, p.out_mode == CARD_OUT_SELECT ? p.state_slot[0] : 0);
         }
 
+        // (every load so far is waited for HERE: a value still in flight at the head of the timestep loop is waited for
+        // inside it, timestep after timestep, together with the weight requests issued before it)
+        float mu_r = mu;
+        asm volatile("" : "+v"(y), "+v"(mu_r));
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) asm volatile("" : "+v"(xin[s]));
         for (int t = p.t_hi; t >= p.t_lo; --t) {
             // next gamma row: t-1, or t_hi again for the next group of chains
             const int tn = t > p.t_lo ? t - 1 : p.t_hi;
             f32x4 gn = {0.f, 0.f, 0.f, 0.f};
             if (tid < G::GROW / 4) gn = *reinterpret_cast<const f32x4*>(p.gtab + (long long)tn * G::GROW + tid * 4);
-            const float z = (t >= 1 && !p.eps_only) ? draw(T - t) : 0.0f;
+            // Everything the tail of the timestep takes from global memory is requested here, unconditionally (from a
+            // stand-in address where the mode has no such input): a load behind a branch makes the compiler wait for ALL
+            // outstanding loads where the branch rejoins, which drained the weight requests in flight once per timestep.
+            const float* const crow = (p.eps_only ? p.gtab : p.coef) + (long long)t * CARD_COEF_COLS;
+            f32x4 ca = *reinterpret_cast<const f32x4*>(crow), cb = *reinterpret_cast<const f32x4*>(crow + 4);
+            const bool noisy = t >= 1 && !p.eps_only;
+            float zin = *(p.noise && noisy ? p.noise + (long long)(T - t - draw0) * p.N + rc : p.ytmean + rr);
+            int slot_sel = *(p.out_mode == CARD_OUT_SELECT ? p.state_slot + (T - t) : reinterpret_cast<const int*>(p.tabs));
+            const float zrng = (noisy && !p.noise) ? draw_rng(T - t) : 0.0f;
             const float* const gl = gbuf + gcur * G::GROW + 4 * g;
 
             f32x4 acc[NTW];
@@ -216,8 +271,12 @@ __global__ __launch_bounds__(kWaves * 64, kWaves == 8 ? 2 : 1) void card_sample_
             };
             // One slab = NKS k-steps: acc[j] += A(slab)[j][ks] * b[OFF + ks].  Ring protocol (3 buffers, ONE barrier per
             // slab, placed mid-slab where every wave has MFMA work on both sides of it):
-            //   top:   slab q+1 (fetched during slab q-1) registers -> buffer (cur+1)%3, last read during slab q-2, which
-            //          every wave had finished before it passed the barrier inside slab q-1; start fetching slab q+2
+            //   first half: slab q+1 (fetched during slab q-1) registers -> buffer (cur+1)%3, last read during slab q-2,
+            //          which every wave had finished before it passed the barrier inside slab q-1; each register set is
+            //          refilled from slab q+2 as soon as it is written.  SPREAD: a share of the words behind each
+            //          k-step's fragment reads instead of all of them at the top, where the 32 KB a workgroup stores at
+            //          once held up the fragment reads queued behind them: 133.8 -> 132.0 ms per 1000 timesteps at 65 536
+            //          chains (and -7 % / -18 % on the four-wave ring forms of the time)
             //   mid:   barrier: slab q+1 is now visible to all waves
             //   end:   the last k-step prefetches the first A fragments of slab q+1 -- no bubble at the boundary
             auto slab = [&](auto nks_tag, auto off_tag, const auto& b) {
@@ -226,27 +285,45 @@ __global__ __launch_bounds__(kWaves * 64, kWaves == 8 ? 2 : 1) void card_sample_
                 // the barrier: mid-slab, and before the first fragment of the NEXT slab is asked for (k-step NKS - DA)
                 constexpr int BAR = NKS / 2 < NKS - DA ? NKS / 2 : NKS - DA;
                 const int nb = cur == G::RING - 1 ? 0 : cur + 1;
-                const float* wl = wbuf + cur * SLAB + lane * 4 + part * NQW * 256;
-                const float* wn = wbuf + nb * SLAB + lane * 4 + part * NQW * 256;
-                stage_to_ring(nb);
-                slab_fetch(nxt);
-                nxt = nxt + 1 == NS ? 0 : nxt + 1;
+                const float* wl = wbuf + cur * SLAB + lane * 4;
+                const float* wn = wbuf + nb * SLAB + lane * 4;
+                if constexpr (!SPREAD) {
+                    stage_to_ring(nb, 0, NST);
+                    slab_fetch(nxt, 0, NST);
+                }
 #pragma unroll
                 for (int s = 0; s < NKS; ++s) {
                     if (s == BAR) __syncthreads();
                     asm volatile("" ::: "memory");       // keep the scheduler from hoisting a whole slab's LDS reads
 #pragma unroll
-                    for (int q = 0; q < NQW; ++q)
+                    for (int q = 0; q < NQ; ++q)
                         afrag[(s + DA) % NA][q] = lds4(s + DA < NKS ? wl + ((s + DA) * NQ + q) * 256 : wn + ((s + DA - NKS) * NQ + q) * 256);
+                    if (SPREAD && s < BAR) {
+                        stage_to_ring(nb, s * NST / BAR, (s + 1) * NST / BAR);
+                        slab_fetch(nxt, s * NST / BAR, (s + 1) * NST / BAR);
+                    }
                     asm volatile("" ::: "memory");
 #pragma unroll
-                    for (int q = 0; q < NQW; ++q) {
+                    for (int q = 0; q < NQ; ++q) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             acc[4 * q + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[s % NA][q][e], b[OFF + s], acc[4 * q + e], 0, 0, 0);
                     }
                 }
+                nxt = nxt + 1 == NS ? 0 : nxt + 1;
                 cur = nb;
+            };
+            // DIRECT: the k-step at ring position P: its fragments were asked for DD k-steps ago; the register set is refilled
+            // at once with the k-step that uses it next
+            auto kstep_direct = [&](int P, float bv) __attribute__((always_inline)) {
+#pragma unroll
+                for (int q = 0; q < NQW; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[4 * q + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[P % DD][q][e], bv, acc[4 * q + e], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < NQW; ++q) frag[P % DD][q] = frag_load(pos_ks((P + DD) % DPT), q);
+                __builtin_amdgcn_sched_barrier(0);      // (left alone, the scheduler sinks the requests to two k-steps ahead of their use)
             };
             auto epilogue = [&](int layer) {
                 if constexpr (SPLIT == 1) {
@@ -258,23 +335,26 @@ __global__ __launch_bounds__(kWaves * 64, kWaves == 8 ? 2 : 1) void card_sample_
                     }
                 } else {
                     // this wave's share to the tile's exchange block, then the whole vector back in register order (own
-                    // share included: static register indices).  The block is rewritten one layer later, behind at least
-                    // one slab barrier that every wave passes only after its reads below have returned (LDS returns in order).
+                    // share included: static register indices).  Two blocks in turn: a block is rewritten two exchanges
+                    // later, behind the barrier of the exchange in between, which a wave passes only after its reads below
+                    // have returned.
+                    float* const xw = xb + xpar * (NT * 256);
 #pragma unroll
                     for (int j = 0; j < NTW; ++j) {
                         const f32x4 gm = lds4(gl + layer * H + 16 * (part * NTW + j));
                         f32x4 v;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = softplus_l2(acc[j][r] * gm[r]);
-                        *reinterpret_cast<f32x4*>(xb + (part * NTW + j) * 256) = v;
+                        *reinterpret_cast<f32x4*>(xw + (part * NTW + j) * 256) = v;
                     }
                     __syncthreads();
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
-                        const f32x4 v = lds4(xb + j * 256);
+                        const f32x4 v = lds4(xw + j * 256);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) h[4 * j + r] = v[r];
                     }
+                    xpar ^= 1;
                 }
             };
 
@@ -292,17 +372,41 @@ __global__ __launch_bounds__(kWaves * 64, kWaves == 8 ? 2 : 1) void card_sample_
             // ---- layer 1 (regression/model.py:48)
             if (g == 0) xin[0] = y;
             load_bias(0);
-            if constexpr (NS1 >= 1) slab(std::integral_constant<int, (KS1 < 8 ? KS1 : 8)>{}, std::integral_constant<int, 0>{}, xin);
-            if constexpr (NS1 >= 2) slab(std::integral_constant<int, (KS1 - 8 < 8 ? KS1 - 8 : 8)>{}, std::integral_constant<int, 8>{}, xin);
-            if constexpr (NS1 >= 3) slab(std::integral_constant<int, (KS1 - 16 < 8 ? KS1 - 16 : 8)>{}, std::integral_constant<int, 16>{}, xin);
-            static_assert(NS1 <= 3, "layer 1 is built for at most 3 slabs (d_in <= 96)");
-            epilogue(0);
-            // ---- layers 2, 3 (:49-50)
+            if constexpr (DIRECT) {
 #pragma unroll
-            for (int layer = 1; layer <= 2; ++layer) {
-                load_bias(layer);
-                hidden_slabs(std::integral_constant<int, 0>{});
-                epilogue(layer);
+                for (int s = 0; s < KS1; ++s) {
+                    if constexpr (L1RES) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag1[s][e], xin[s], acc[e], 0, 0, 0);
+                    } else {
+                        kstep_direct(s, xin[s]);
+                    }
+                }
+                epilogue(0);
+                // the next gamma row, published here: the two exchange barriers still ahead in this timestep lie between
+                // this store and its readers, and the barrier just passed between the row's last readers and this store
+                if (SPLIT > 1 && tid < G::GROW / 4) *reinterpret_cast<f32x4*>(gbuf + (gcur ^ 1) * G::GROW + tid * 4) = gn;
+                // ---- layers 2, 3 (:49-50)
+#pragma unroll
+                for (int layer = 1; layer <= 2; ++layer) {
+                    load_bias(layer);
+#pragma unroll
+                    for (int ks = 0; ks < G::KSH; ++ks) kstep_direct(DP1 + (layer - 1) * G::KSH + ks, h[ks]);
+                    epilogue(layer);
+                }
+            } else {
+                if constexpr (NS1 >= 1) slab(std::integral_constant<int, (KS1 < 8 ? KS1 : 8)>{}, std::integral_constant<int, 0>{}, xin);
+                if constexpr (NS1 >= 2) slab(std::integral_constant<int, (KS1 - 8 < 8 ? KS1 - 8 : 8)>{}, std::integral_constant<int, 8>{}, xin);
+                if constexpr (NS1 >= 3) slab(std::integral_constant<int, (KS1 - 16 < 8 ? KS1 - 16 : 8)>{}, std::integral_constant<int, 16>{}, xin);
+                static_assert(NS1 <= 3, "layer 1 is built for at most 3 slabs (d_in <= 96)");
+                epilogue(0);
+                // ---- layers 2, 3 (:49-50)
+#pragma unroll
+                for (int layer = 1; layer <= 2; ++layer) {
+                    load_bias(layer);
+                    hidden_slabs(std::integral_constant<int, 0>{});
+                    epilogue(layer);
+                }
             }
             // ---- lin4 (:51): per-lane partial over its 64 features, then across the four lane groups
             float dot = 0.0f;
@@ -319,19 +423,19 @@ __global__ __launch_bounds__(kWaves * 64, kWaves == 8 ? 2 : 1) void card_sample_
             if (p.eps_only) {
                 if (valid && g == 0 && part == 0) p.out[row] = eps;
             } else {
-                // posterior update, regression/diffusion_utils.py:83-89 (t >= 1) / :101-103 (t == 0)
-                const float* c = p.coef + (long long)t * CARD_COEF_COLS;
-                const float y0r = c[CARD_COEF_INV_SQRT_AB] * ((y - c[CARD_COEF_ONE_M_SQRT_AB] * mu) - eps * c[CARD_COEF_SOMAB]);
-                if (t >= 1) {
-                    const float yh = (c[CARD_COEF_G0] * y0r + c[CARD_COEF_G1] * y) + c[CARD_COEF_G2] * mu;
-                    y = yh + c[CARD_COEF_SIGMA] * z;
-                } else {
-                    y = y0r;
-                }
-                store_state(T - t, y);
+                // (the values requested at the top are first touched here: pinned, or the compiler moves a copy -- and with
+                // it the wait for every load in flight -- to the head of the timestep)
+                asm volatile("" : "+v"(ca), "+v"(cb), "+v"(zin), "+v"(slot_sel));
+                const CoefRow cf = {ca[CARD_COEF_INV_SQRT_AB], ca[CARD_COEF_ONE_M_SQRT_AB], ca[CARD_COEF_SOMAB], ca[CARD_COEF_G0],
+                                    cb[CARD_COEF_G1 - 4], cb[CARD_COEF_G2 - 4], cb[CARD_COEF_SIGMA - 4]};
+                y = posterior_update(cf, t, y, mu_r, eps, p.noise ? zin : zrng);
+                store_state(T - t, y, slot_sel);
             }
             // publish the next gamma row (read after the next step's first slab barrier)
-            if (tid < G::GROW / 4) *reinterpret_cast<f32x4*>(gbuf + (gcur ^ 1) * G::GROW + tid * 4) = gn;
+            // (DIRECT with a tile per wave has no barrier of its own in the timestep: one here, behind the store; the
+            // row's last readers passed the previous timestep's)
+            if (!(DIRECT && SPLIT > 1) && tid < G::GROW / 4) *reinterpret_cast<f32x4*>(gbuf + (gcur ^ 1) * G::GROW + tid * 4) = gn;
+            if constexpr (DIRECT && SPLIT == 1) __syncthreads();
             gcur ^= 1;
         }
         if (p.out_mode == CARD_OUT_LAST && !p.eps_only && valid && g == 0 && part == 0) p.out[row] = y;
@@ -401,9 +505,10 @@ template <int W, int S>
 stream_kernel_t stream_kernel_pick(int ks1) {
     // (the packed image zero-fills a layer-1 slab beyond d_in and the kernel feeds zeros for columns beyond d_in, so a
     // model packed for two k-steps also runs, with the same results, on the kernel that walks four)
-    if (S > 1 && ks1 == 2) ks1 = 4;
+    constexpr bool direct = W == kWavesSmall;
+    if (direct && ks1 == 2) ks1 = 4;
     switch (ks1) {
-        case 2: if constexpr (S == 1) return card_sample_stream_kernel<256, 2, W, S>; else return nullptr;
+        case 2: if constexpr (!direct) return card_sample_stream_kernel<256, 2, W, S>; else return nullptr;
         case 4: return card_sample_stream_kernel<256, 4, W, S>;
         case 8: return card_sample_stream_kernel<256, 8, W, S>;
         case 16: return card_sample_stream_kernel<256, 16, W, S>;
@@ -412,11 +517,18 @@ stream_kernel_t stream_kernel_pick(int ks1) {
     }
 }
 
-// waves per workgroup (8 | 4) and waves per tile (1 | 4)
+// waves per workgroup (8: slab ring | 4: fragments straight from L2) and, with 4, waves per tile (1 | 4)
 stream_kernel_t stream_kernel_for(int H, int ks1, int waves, int split = 1) {
     if (H != 256) return nullptr;
-    if (waves == kWavesFull) return split == 4 ? stream_kernel_pick<kWavesFull, 4>(ks1) : stream_kernel_pick<kWavesFull, 1>(ks1);
+    if (waves == kWavesFull) return split == 1 ? stream_kernel_pick<kWavesFull, 1>(ks1) : nullptr;
     return split == 4 ? stream_kernel_pick<kWavesSmall, 4>(ks1) : stream_kernel_pick<kWavesSmall, 1>(ks1);
+}
+
+// dynamic LDS of a form: tables + two gamma rows; + the slab ring (8 waves) or the two activation exchange blocks (shared tile)
+size_t stream_lds_bytes(int H, int waves, int split) {
+    const size_t tabs = (size_t)(4 * H + 4 + 2 * 3 * H) * sizeof(float);
+    if (waves == kWavesFull) return tabs + (size_t)3 * kSlabKs * (H / 16) * 64 * sizeof(float);
+    return tabs + (split == 4 ? (size_t)2 * (H / 16) * 256 * sizeof(float) : 0);
 }
 
 }  // namespace
@@ -434,17 +546,16 @@ int stream_create(card_sampler* s, const card_model_desc* d, hipStream_t stream)
     const int ns1 = (ks1 + kSlabKs - 1) / kSlabKs, NSH = H / 32, SLAB = kSlabKs * (H / 16) * 64;
     s->k1 = ks1;
     s->kernel = reinterpret_cast<void*>(kern);
-    s->lds_bytes = (size_t)(3 * SLAB + 4 * H + 4 + 2 * 3 * H) * sizeof(float);
+    s->lds_bytes = stream_lds_bytes(H, kWavesFull, 1);
     HIP_TRY(hipMalloc(&s->wpk, (size_t)(ns1 + 2 * NSH) * SLAB * sizeof(float)));
     HIP_TRY(hipMalloc(&s->w1s, (size_t)(4 * H + 4) * sizeof(float)));
     HIP_TRY(hipMalloc(&s->gtab, (size_t)d->n_embed * 3 * H * sizeof(float)));
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
-    // (+ the activation exchange of the forms that split a tile over 2 / 4 waves: 16 KB per tile of the workgroup)
-    for (int split : {1, 4})
-        HIP_TRY(hipFuncSetAttribute((const void*)stream_kernel_for(H, ks1, kWavesSmall, split), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(s->lds_bytes + (split > 1 ? (kWavesSmall / split) * (H / 16) * 256 * sizeof(float) : 0))));
-    HIP_TRY(hipFuncSetAttribute((const void*)stream_kernel_for(H, ks1, kWavesFull, 4), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(s->lds_bytes + (kWavesFull / 4) * (H / 16) * 256 * sizeof(float))));
+    // workgroups of the shared-tile form that fit a CU (two: it is built within 256 registers)
+    int occ = 1;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)stream_kernel_for(H, ks1, kWavesSmall, 4), kWavesSmall * 64,
+                                                         stream_lds_bytes(H, kWavesSmall, 4)));
+    s->coop_blocks = occ < 1 ? 1 : occ > 2 ? 2 : occ;
     stream_pack_kernel<<<512, 256, 0, stream>>>(d->W[0], d->W[1], d->W[2], H, d_in, ns1, s->wpk);
     stream_tabs_kernel<<<1, 256, 0, stream>>>(d->b[0], d->b[1], d->b[2], d->W4, d->b4, H, s->w1s);
     stream_gamma_kernel<<<512, 256, 0, stream>>>(d->gamma[0], d->gamma[1], d->gamma[2], d->n_embed, H, s->gtab);
@@ -467,35 +578,34 @@ int stream_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     p.T = r.T; p.t_hi = r.t_hi; p.t_lo = r.t_lo;
     p.x_dim = s->x_dim; p.cat_x = s->cat_x; p.cat_y_pred = s->cat_y_pred;
     p.out_mode = r.out_mode; p.eps_only = r.eps_only; p.n_z = r.n_z;
-    // Small batches (at most num_cu * 4 waves * 16 chains = 16 384 on 256 CUs): four waves per workgroup, one per SIMD,
-    // so every SIMD of the chip gets a tile; the 8-wave form would run them on half of the CUs.  CARD_AMD_STREAM=big
-    // keeps the 8-wave form (A/B); results are identical (same per-chain arithmetic).
-    // Forms by batch size (256 CUs): above num_cu * 64 chains eight waves per workgroup, a tile each (two waves per SIMD);
-    // up to num_cu * 64 = 16 384 four waves, a tile each, so that every CU gets a workgroup; up to num_cu * 32 = 8 192 eight
-    // waves with every tile shared by four of them (two tiles per CU, two waves per SIMD: a tile-timestep is a quarter as
-    // long and the two tiles cover each other's waits); up to num_cu * 16 = 4 096 four waves sharing one tile per CU.
+    // Forms by batch size (256 CUs): above num_cu * 64 = 16 384 chains eight waves per workgroup, a tile each, weights
+    // through the LDS slab ring; up to there four waves (one per SIMD) that take their fragments straight from L2: a tile
+    // each down to num_cu * 32 chains, below that ONE tile shared by the four waves of a workgroup -- two such workgroups
+    // per CU between num_cu * 16 and num_cu * 32 chains (a workgroup whose CU has no second slot walks a second tile instead).
     // CARD_AMD_STREAM=big: always the first form; nosplit: never a shared tile (tests, A/B; results are identical).
     const long long per_cu = (p.N + s->num_cu - 1) / s->num_cu;
-    int waves = kWavesFull, split = 1;
+    int waves = kWavesFull, split = 1, wg_per_cu = 1;
     if (!s->tune.stream_big && per_cu <= kWavesSmall * kTile) {
         waves = kWavesSmall;
-        if (!s->tune.stream_nosplit && per_cu <= kTile) split = 4;
-        else if (!s->tune.stream_nosplit && per_cu <= 2 * kTile) { waves = kWavesFull; split = 4; }
+        if (!s->tune.stream_nosplit && per_cu <= 2 * kTile) {
+            split = 4;
+            if (per_cu > kTile) wg_per_cu = s->coop_blocks;
+        }
     }
     if (r.plan)      // layer 1 on MFMA every step with K padded to 4 * ks1 columns, two H x H layers, lin4 (VALU)
-        r.plan->executed = 2.0 * s->hidden * (4 * ((split > 1 && s->k1 == 2) ? 4 : s->k1) + 2 * s->hidden) + 2.0 * s->hidden;
+        r.plan->executed = 2.0 * s->hidden * (4 * ((waves == kWavesSmall && s->k1 == 2) ? 4 : s->k1) + 2 * s->hidden) + 2.0 * s->hidden;
     stream_kernel_t kern = stream_kernel_for(s->hidden, s->k1, waves, split);
-    const size_t lds_bytes = s->lds_bytes + (split > 1 ? (size_t)(waves / split) * (s->hidden / 16) * 256 * sizeof(float) : 0);
+    const size_t lds_bytes = stream_lds_bytes(s->hidden, waves, split);
     // launches of at most num_cu workgroups x kGroupsPerWg groups x 128 chains: every workgroup walks the same
     // number of groups (the kernel's barriers need that) and one launch stays well under a second
     const long long group = waves / split * kTile;
-    const long long chunk = (long long)s->num_cu * kGroupsPerWg * group;
+    const long long chunk = (long long)s->num_cu * wg_per_cu * kGroupsPerWg * group;
     for (long long b = 0; b < p.N; b += chunk) {
         p.n_begin = b;
         p.n_end = b + chunk < p.N ? b + chunk : p.N;
         const long long groups = (p.n_end - p.n_begin + group - 1) / group;
-        const long long grid = groups < s->num_cu ? groups : s->num_cu;
-        CARD_LAUNCH(r, split == 4 ? (waves == kWavesFull ? "card_sample_stream_kernel (8 waves, tile over 4 waves)" : "card_sample_stream_kernel (4 waves, tile over 4 waves)")
+        const long long grid = groups < s->num_cu * wg_per_cu ? groups : s->num_cu * wg_per_cu;
+        CARD_LAUNCH(r, split == 4 ? "card_sample_stream_kernel (4 waves, tile over 4 waves)"
                        : waves == kWavesSmall ? "card_sample_stream_kernel (4 waves)" : "card_sample_stream_kernel", true,
                     kern<<<dim3((unsigned)grid), dim3(waves * 64), lds_bytes, stream>>>(p));
     }

@@ -140,10 +140,10 @@ def test_four_wave_and_eight_wave_forms_agree_bit_for_bit(N, monkeypatch):
 
 @pytest.mark.parametrize("N", [16, 700, 4096, 4097, 8192])
 def test_tile_split_over_waves_agrees_bit_for_bit(N, monkeypatch, wave_form):
-    """Up to num_cu * 32 chains a 16-chain tile is shared by 4 waves (each computes a share of every
-    layer's output features and the activations are traded through LDS, card_stream.hip SPLIT): every output element is the
-    same FMA chain over k, so CARD_AMD_STREAM=nosplit (one wave per tile) gives the same bits -- RNG mode, every state,
-    in-kernel row tiling, eps_theta -- and the plan names the form."""
+    """Up to num_cu * 32 chains a 16-chain tile is shared by the 4 waves of a workgroup (each computes a share of every
+    layer's output features and the activations are traded through LDS, card_stream.hip SPLIT; above num_cu * 16 chains two
+    such workgroups per CU): every output element is the same FMA chain over k, so CARD_AMD_STREAM=nosplit (one wave per
+    tile) gives the same bits -- RNG mode, every state, in-kernel row tiling, eps_theta -- and the plan names the form."""
     if wave_form != "small4":
         pytest.skip("the split forms belong to the four-wave form")
     T, n_z = 9, 1
@@ -158,7 +158,7 @@ def test_tile_split_over_waves_agrees_bit_for_bit(N, monkeypatch, wave_form):
         outs.append(s.run(cuda(x), cuda(y0), cuda(mu), coef, T, **kw))
         eps.append(s.eps_theta(cuda(x), cuda(y0), cuda(y0), 4))
         form = s.run(cuda(x), cuda(y0), cuda(mu), coef, T, plan=True, **kw)["kernel"]
-        want = "(4 waves)" if env or N > 8192 else ("(4 waves, tile over 4 waves)" if N <= 4096 else "(8 waves, tile over 4 waves)")      # 256 CUs
+        want = "(4 waves)" if env or N > 8192 else "(4 waves, tile over 4 waves)"      # 256 CUs
         assert want in form, form
     assert torch.equal(outs[0], outs[1]) and torch.equal(eps[0], eps[1]) and torch.isfinite(outs[0]).all()
     if N >= 700:        # rows tiled in-kernel: 7 chains per row, ragged against the 16-chain tiles

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from card_amd.sampler import Sampler, make_coef_table
 from card_amd.synth import guided_state_dict, make_schedule
 
-dev, T, x_dim, H = "cuda:0", 1000, 13, 256
+dev, T, x_dim, H = "cuda:0", 1000, int(os.environ.get("XDIM", 13)), 256
 sd = guided_state_dict(x_dim, T, hidden=H)
 alphas, _, omabs = make_schedule("linear", T, 1e-4, 0.02)
 coef = make_coef_table(alphas, omabs).to(dev)
