@@ -32,8 +32,8 @@ inline bool card_plan_note(CardPlanRec* pl, const char* name, bool dominant) {
 // when a sampler is created (card_tune_from_env, card_api.hip) and kept in the sampler; a run reads no environment.
 //   CARD_AMD_COOP     regression, hidden 128:  off (0) = persistent kernel for every batch size | force (2) = cooperative
 //                     kernel for every batch size | no16 = no 16-chain-tile form | no2 = no time-sliced paired form
-//   CARD_AMD_STREAM   regression, hidden 256:  off (0) = GEMM back end instead | big = no four-wave small-batch form |
-//                     nosplit = one wave per tile also below num_cu * 32 chains
+//   CARD_AMD_STREAM   regression, hidden 256:  off (0) = GEMM back end instead | big = eight-wave ring form only |
+//                     nosplit = never a tile shared by four waves
 //   CARD_AMD_CLSCOOP  classification, F = 128: off (0) = GEMM back end instead | noslice = no round-robin time slicing
 //   CARD_AMD_WIDE     GEMM back end:           gemmhead = lin4 as a GEMM launch also up to 32 classes | notail = no 64 x 64 tail tiles
 //   CARD_AMD_ARITH    split = CARD_ARITH_SPLIT_BF16 for calls that leave card_run_args.arith at 0
@@ -77,7 +77,7 @@ struct card_sampler {
     // ---- CARD_VARIANT_GUIDED (card_guided.hip)
     int nqs;           // k-step groups of the hoisted static columns of W1 (card_clscoop.hip: of the class columns)
     int k1;            // card_stream.hip: k-steps of layer 1
-    int coop_blocks;   // > 0: workgroups per CU of the cooperative small-batch kernel (0: not available)
+    int coop_blocks;   // > 0: workgroups per CU of the cooperative small-batch kernel (0: not available); card_stream.hip: of its shared-tile form
     float* wpk;    // packed LDS image
     float* gtab;   // (n_embed, 3, H) gamma * log2e [* bn_scale]
     float* w1s;    // hoist: packed static columns of W1

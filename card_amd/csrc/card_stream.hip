@@ -531,6 +531,43 @@ size_t stream_lds_bytes(int H, int waves, int split) {
     return tabs + (split == 4 ? (size_t)2 * (H / 16) * 256 * sizeof(float) : 0);
 }
 
+// A form of the kernel and what one ROUND of it costs (every resident tile advances one timestep), relative to the
+// shared-tile form with one workgroup per CU.  Measured per 1000 timesteps at x_dim 13 (profiles/r03_small_batch_latency_h256.jsonl:
+// 66.0 / 33.5 / 17.7 / 9.9 ms; x_dim 90: 68 / 38.8 / 19.7 / 11.1): ratios of cycle counts of MFMA-bound loops fed from L2,
+// they do not move with the shader clock.
+struct StreamForm { int waves, split, wg_per_cu; double round_cost; };
+struct StreamSeg { int form; long long chains; };
+constexpr double kRound8 = 6.67, kRound4 = 3.38, kRoundS2 = 1.79, kRoundS1 = 1.0;
+constexpr double kLaunchCost = 0.5;      // a launch (~5 us) in the same unit (a shared-tile round is ~9.9 us per timestep)
+
+// Cheapest cut of `rem` chains into segments of forms f0..nf-1 (ordered by falling round capacity cap[f]): either all of
+// them in rounds of one form, or the whole rounds of a form and the rest in smaller forms.  At most one segment per form.
+double stream_plan(const StreamForm* forms, int nf, const long long* cap, long long rem, int f0, int steps, StreamSeg* out, int* n_out) {
+    double best = 1e300;
+    *n_out = 0;
+    for (int g = f0; g < nf; ++g) {
+        const long long whole = rem / cap[g], rest = rem - whole * cap[g];
+        const double all = (double)(whole + (rest ? 1 : 0)) * forms[g].round_cost * steps + kLaunchCost;
+        if (all < best) {
+            best = all;
+            out[0] = {g, rem};
+            *n_out = 1;
+        }
+        if (whole >= 1 && rest > 0 && g + 1 < nf) {
+            StreamSeg sub[4];
+            int ns = 0;
+            const double c = (double)whole * forms[g].round_cost * steps + kLaunchCost + stream_plan(forms, nf, cap, rest, g + 1, steps, sub, &ns);
+            if (c < best) {
+                best = c;
+                out[0] = {g, whole * cap[g]};
+                for (int i = 0; i < ns; ++i) out[1 + i] = sub[i];
+                *n_out = 1 + ns;
+            }
+        }
+    }
+    return best;
+}
+
 }  // namespace
 
 bool stream_supports(const card_model_desc* d, int d_in, const CardTune& tune) {
@@ -578,36 +615,49 @@ int stream_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     p.T = r.T; p.t_hi = r.t_hi; p.t_lo = r.t_lo;
     p.x_dim = s->x_dim; p.cat_x = s->cat_x; p.cat_y_pred = s->cat_y_pred;
     p.out_mode = r.out_mode; p.eps_only = r.eps_only; p.n_z = r.n_z;
-    // Forms by batch size (256 CUs): above num_cu * 64 = 16 384 chains eight waves per workgroup, a tile each, weights
-    // through the LDS slab ring; up to there four waves (one per SIMD) that take their fragments straight from L2: a tile
-    // each down to num_cu * 32 chains, below that ONE tile shared by the four waves of a workgroup -- two such workgroups
-    // per CU between num_cu * 16 and num_cu * 32 chains (a workgroup whose CU has no second slot walks a second tile instead).
-    // CARD_AMD_STREAM=big: always the first form; nosplit: never a shared tile (tests, A/B; results are identical).
-    const long long per_cu = (p.N + s->num_cu - 1) / s->num_cu;
-    int waves = kWavesFull, split = 1, wg_per_cu = 1;
-    if (!s->tune.stream_big && per_cu <= kWavesSmall * kTile) {
-        waves = kWavesSmall;
-        if (!s->tune.stream_nosplit && per_cu <= 2 * kTile) {
-            split = 4;
-            if (per_cu > kTile) wg_per_cu = s->coop_blocks;
+    // Forms (256 CUs): eight waves per workgroup, a tile each, weights through the LDS slab ring (a round = num_cu * 128
+    // chains); four waves (one per SIMD) that take their fragments straight from L2, a tile each (num_cu * 64); ONE tile
+    // shared by the four waves of a workgroup, two such workgroups per CU (num_cu * 32) or one (num_cu * 16).  A call is cut
+    // into segments of whole rounds (stream_plan above): 20 000 chains are one round of the second form + one of the
+    // last, not one round of the first with 39 % of the CUs idle.  Results do not depend on the cut (a chain's arithmetic
+    // is the same in every form, its noise keyed by its element index).
+    // CARD_AMD_STREAM=big: only the first form; nosplit: never a shared tile (tests, A/B).
+    StreamForm forms[4];
+    int nf = 0;
+    forms[nf++] = {kWavesFull, 1, 1, kRound8};
+    if (!s->tune.stream_big) {
+        forms[nf++] = {kWavesSmall, 1, 1, kRound4};
+        if (!s->tune.stream_nosplit) {
+            if (s->coop_blocks >= 2) forms[nf++] = {kWavesSmall, 4, 2, kRoundS2};
+            forms[nf++] = {kWavesSmall, 4, 1, kRoundS1};
         }
     }
+    long long cap[4];
+    for (int f = 0; f < nf; ++f) cap[f] = (long long)s->num_cu * forms[f].wg_per_cu * (forms[f].waves / forms[f].split) * kTile;
+    StreamSeg seg[4];
+    int nseg = 0;
+    stream_plan(forms, nf, cap, p.N, 0, r.t_hi - r.t_lo + 1, seg, &nseg);
     if (r.plan)      // layer 1 on MFMA every step with K padded to 4 * ks1 columns, two H x H layers, lin4 (VALU)
-        r.plan->executed = 2.0 * s->hidden * (4 * ((waves == kWavesSmall && s->k1 == 2) ? 4 : s->k1) + 2 * s->hidden) + 2.0 * s->hidden;
-    stream_kernel_t kern = stream_kernel_for(s->hidden, s->k1, waves, split);
-    const size_t lds_bytes = stream_lds_bytes(s->hidden, waves, split);
-    // launches of at most num_cu workgroups x kGroupsPerWg groups x 128 chains: every workgroup walks the same
-    // number of groups (the kernel's barriers need that) and one launch stays well under a second
-    const long long group = waves / split * kTile;
-    const long long chunk = (long long)s->num_cu * wg_per_cu * kGroupsPerWg * group;
-    for (long long b = 0; b < p.N; b += chunk) {
-        p.n_begin = b;
-        p.n_end = b + chunk < p.N ? b + chunk : p.N;
-        const long long groups = (p.n_end - p.n_begin + group - 1) / group;
-        const long long grid = groups < s->num_cu * wg_per_cu ? groups : s->num_cu * wg_per_cu;
-        CARD_LAUNCH(r, split == 4 ? "card_sample_stream_kernel (4 waves, tile over 4 waves)"
-                       : waves == kWavesSmall ? "card_sample_stream_kernel (4 waves)" : "card_sample_stream_kernel", true,
-                    kern<<<dim3((unsigned)grid), dim3(waves * 64), lds_bytes, stream>>>(p));
+        r.plan->executed = 2.0 * s->hidden * (4 * ((forms[seg[0].form].waves == kWavesSmall && s->k1 == 2) ? 4 : s->k1) + 2 * s->hidden) + 2.0 * s->hidden;
+    long long b = 0;
+    for (int i = 0; i < nseg; ++i) {
+        const StreamForm& f = forms[seg[i].form];
+        stream_kernel_t kern = stream_kernel_for(s->hidden, s->k1, f.waves, f.split);
+        const size_t lds_bytes = stream_lds_bytes(s->hidden, f.waves, f.split);
+        // launches of at most kGroupsPerWg rounds: every workgroup walks the same number of tile groups (the kernel's
+        // barriers need that) and one launch stays well under a second
+        const long long group = f.waves / f.split * kTile, slots = (long long)s->num_cu * f.wg_per_cu;
+        const long long chunk = slots * kGroupsPerWg * group, end = b + seg[i].chains;
+        for (; b < end; b += chunk) {
+            p.n_begin = b;
+            p.n_end = b + chunk < end ? b + chunk : end;
+            const long long groups = (p.n_end - p.n_begin + group - 1) / group;
+            const long long grid = groups < slots ? groups : slots;
+            CARD_LAUNCH(r, f.split == 4 ? "card_sample_stream_kernel (4 waves, tile over 4 waves)"
+                           : f.waves == kWavesSmall ? "card_sample_stream_kernel (4 waves)" : "card_sample_stream_kernel", true,
+                        kern<<<dim3((unsigned)grid), dim3(f.waves * 64), lds_bytes, stream>>>(p));
+        }
+        b = end;
     }
     return CARD_OK;
 }

@@ -40,10 +40,18 @@ def test_plan_names_the_kernels_of_the_baseline_shapes():
     p = s.run(x, y0, y0, coef, 1000, n_z=200, plan=True)
     assert p["kernel"] == "card_sample_coop2_kernel" and 2 <= p["launches"] <= 8
     assert s.run(x, y0, y0, coef, 1000, n_z=200, arith=_lib.ARITH_SPLIT_BF16, plan=True)["kernel"] == "card_sample_split_kernel"
-    # hidden 256: the streamed kernel, four-wave form up to 16 384 chains
-    s, x, y0, coef = _reg(13, 164, hidden=256, T=20)
-    assert s.run(x, y0, y0, coef, 20, n_z=100, plan=True)["kernel"] == "card_sample_stream_kernel"
-    assert s.run(x[:100], y0[:100], y0[:100], coef, 20, n_z=100, plan=True)["kernel"] == "card_sample_stream_kernel (4 waves)"
+    # hidden 256: the streamed kernel cuts a call into whole rounds of its forms (card_stream.hip stream_plan): 40 000 chains =
+    # one round of the eight-wave form + one of the shared-tile form; 16 400 = a round of the four-wave form + one tile;
+    # 10 000 = two shared-tile workgroups per CU, then one; 4 000: a single launch
+    s, x, y0, coef = _reg(13, 400, hidden=256, T=20)
+    p = s.run(x, y0, y0, coef, 20, n_z=100, plan=True)
+    assert p["kernel"] == "card_sample_stream_kernel" and p["launches"] == 2
+    p = s.run(x[:164], y0[:164], y0[:164], coef, 20, n_z=100, plan=True)
+    assert p["kernel"] == "card_sample_stream_kernel (4 waves)" and p["launches"] == 2
+    p = s.run(x[:100], y0[:100], y0[:100], coef, 20, n_z=100, plan=True)
+    assert p["kernel"] == "card_sample_stream_kernel (4 waves, tile over 4 waves)" and p["launches"] == 2
+    p = s.run(x[:40], y0[:40], y0[:40], coef, 20, n_z=100, plan=True)
+    assert p["kernel"] == "card_sample_stream_kernel (4 waves, tile over 4 waves)" and p["launches"] == 1
 
 
 def test_plan_of_the_classification_heads_and_no_side_effects():

@@ -125,8 +125,9 @@ def test_stream_kernel_several_launches():
     assert norm_rel_err(a.cpu(), b.cpu()) <= TOL
 
 
-@pytest.mark.parametrize("N", [64, 1000, 16384])
+@pytest.mark.parametrize("N", [64, 1000, 16384, 20000, 40000])
 def test_four_wave_and_eight_wave_forms_agree_bit_for_bit(N, monkeypatch):
+    """(20 000 and 40 000 chains: calls the default dispatch cuts into rounds of different forms, card_stream.hip stream_plan)"""
     T = 7
     sd, x, y0, mu, _, alphas, omabs = _case(13, T, N, 77)
     coef = cuda(make_coef_table(alphas, omabs))
