@@ -72,7 +72,7 @@ struct GuidedParams {
     int nqs;              // ceil((d_in - 1) / 8)
     // time-sliced cooperative launches (card_sample_coop2_kernel): this launch is slice sl_k of sl_K
     int sl_k, sl_K, sl_nsingle, sl_S, sl_L;
-    float* ybuf;          // (N) chain states handed from one slice to the next
+    float* ybuf;          // (n_end - n_begin) chain states handed from one slice to the next
     const float* wpk16;   // card_sample_coop16_kernel: W2 | W3 in 16x16x4 fragment order (x ln2)
     const float* w1s16;   // ... and the static columns of W1: [(w, mb), q, e][64]
 };
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop2_kernel(con
     __syncthreads();
     if (active) {
         if (!first_seg) {
-            y = p.ybuf[rc];
+            y = p.ybuf[rc - p.n_begin];
         } else if (p.y_init) {
             y = p.y_init[rc];
         } else {
@@ -768,7 +768,7 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop2_kernel(con
         }
     }
     if (valid && hh == 0 && w == 0 && !p.eps_only) {
-        if (!last_seg) p.ybuf[row] = y;
+        if (!last_seg) p.ybuf[row - p.n_begin] = y;
         else if (p.out_mode == CARD_OUT_LAST) p.out[row] = y;
     }
 }
@@ -974,7 +974,7 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
     __syncthreads();
     if (active) {
         if (!first_seg) {
-            y = p.ybuf[rc];
+            y = p.ybuf[rc - p.n_begin];
         } else if (p.y_init) {
             y = p.y_init[rc];
         } else {
@@ -1110,7 +1110,7 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
 #endif
     }
     if (valid && g == 0 && w == 0 && !p.eps_only) {
-        if (!last_seg) p.ybuf[row] = y;
+        if (!last_seg) p.ybuf[row - p.n_begin] = y;
         else if (p.out_mode == CARD_OUT_LAST) p.out[row] = y;
     }
 }
@@ -1242,8 +1242,90 @@ void guided_destroy(card_sampler* s) {
 // Measured on MI355X, tools/bench_small.py (profiles/r03_small_batch_ab.jsonl):
 constexpr double kRho16 = 1.68;    // 16-chain tiles: timestep of two tiles sharing a CU (5.27 us) / of one tile alone with every CU busy (3.14 us)
 constexpr double kRho32 = 1.717;   // 32-chain tiles: 9.1 us / 5.3 us
-constexpr int kCoopMaxRoundsX2 = 7;  // cooperative form up to 3.5 rounds of 2 tiles per CU (9.0 ms per round against 18.0 / 33.8 ms
-                                     // per 4 / 8 tiles per CU on the persistent kernel)
+// What a timestep of each form costs (us on MI355X, profiles/r03_small_batch_latency.jsonl; used as ratios, see above):
+constexpr double kCostPers = 33.6;       // persistent kernel, a round of num_cu * 8 tiles (two waves per SIMD)
+constexpr double kCostPersHalf = 18.0;   // ... up to num_cu * 4 tiles (every tile has a SIMD to itself)
+constexpr double kCostCoopRound = 9.0;   // cooperative kernel, a round of two 32-chain tiles per CU
+constexpr double kCostLone16 = 3.1;      // 16-chain tiles, at most one per CU; time-sliced forms in between: linear up to a round
+constexpr double kCostLaunch = 5.0;      // a launch
+constexpr double kPlanMinGain = 0.03;    // the last partial round of a call leaves the persistent kernel only if that saves this share of the call
+
+namespace {
+
+// [b, e), less than one round of the cooperative kernel (two 32-chain tiles per CU), on the small-batch forms
+int guided_small(const card_sampler* s, const CardRun& r, RunParams& p, long long b, long long e, unsigned long long scratch_bytes, hipStream_t stream) {
+    const int n_steps = p.t_hi - p.t_lo + 1;
+    p.n_begin = b;
+    p.n_end = e;
+    const long long n = e - b, tiles_total = (n + kTileM - 1) / kTileM;
+    const bool ybuf_fits = (unsigned long long)n * sizeof(float) <= scratch_bytes;   // chain states between time slices
+    // Up to two 16-chain tiles per CU (8 192 chains on 256 CUs; BASELINE configs[0] is 5 100): the 16-chain-tile kernel,
+    // one tile per CU up to num_cu tiles, the time-sliced single / paired scheme between num_cu and 2 x num_cu.
+    // (a CU sharing two 16-chain tiles takes 5.3 us per timestep, one 32-chain tile alone 5.3 us: above 15/8 tiles
+    // per CU the 32-chain form below is as fast)
+    const long long tiles16 = (n + kT16 - 1) / kT16;
+    if (s->coop_blocks == 2 && !s->tune.coop_no16 && s->wpk16 && tiles16 <= 2LL * s->num_cu - s->num_cu / 8) {
+        long long n_single = tiles16 <= s->num_cu ? tiles16 : 2LL * s->num_cu - tiles16;
+        int K = 1, S = n_steps, L = n_steps;
+        if (tiles16 > s->num_cu && n_single > 0 && !p.eps_only && n_steps >= 64 && ybuf_fits) {
+            const int K2 = (int)((tiles16 + n_single - 1) / n_single);
+            const int S2 = (int)((double)n_steps / ((double)(K2 - 1) + kRho16) + 0.5);
+            const int L2 = n_steps - (K2 - 1) * S2;
+            if (K2 <= 8 && S2 >= 8 && L2 >= S2) { K = K2; S = S2; L = L2; }
+        }
+        if (K == 1 && tiles16 > s->num_cu) n_single = 2LL * s->num_cu - tiles16 > 0 ? 2LL * s->num_cu - tiles16 : 0;
+        p.ybuf = p.ws;
+        p.sl_K = K; p.sl_nsingle = (int)n_single; p.sl_S = S; p.sl_L = L;
+        for (int k = 0; k < K; ++k) {
+            long long n_s = n_single > 0 ? tiles16 - (long long)k * n_single : 0;
+            n_s = n_s > n_single ? n_single : (n_s < 0 ? 0 : n_s);
+            const long long grid = n_s + (tiles16 - n_s + 1) / 2;
+            p.sl_k = k;
+            CARD_LAUNCH(r, "card_sample_coop16_kernel", true,
+                        card_sample_coop16_kernel<<<dim3((unsigned)grid), dim3(kCoop2Threads), (size_t)kCoop16LdsFloats * sizeof(float), stream>>>(p));
+        }
+        return CARD_OK;
+    }
+    // Between one and two tiles per CU (the reference's Year minibatch: 12 800 chains = 400 tiles): the time-sliced
+    // paired form, see card_sample_coop2_kernel.  n_single CUs' worth of tiles run alone in each slice; every tile
+    // does so in exactly one of the K slices.
+    if (s->coop_blocks == 2 && !s->tune.coop_no2 && !p.eps_only && tiles_total > s->num_cu &&
+        tiles_total < 2LL * s->num_cu && n_steps >= 64 && ybuf_fits) {
+        const long long n_single = 2LL * s->num_cu - tiles_total;
+        const int K = (int)((tiles_total + n_single - 1) / n_single);
+        const int S = (int)((double)n_steps / ((double)(K - 1) + kRho32) + 0.5);
+        const int L = n_steps - (K - 1) * S;
+        if (K <= 8 && S >= 8 && L >= S) {
+            p.ybuf = p.ws;
+            p.sl_K = K; p.sl_nsingle = (int)n_single; p.sl_S = S; p.sl_L = L;
+            for (int k = 0; k < K; ++k) {
+                long long n_s = tiles_total - (long long)k * n_single;
+                n_s = n_s > n_single ? n_single : n_s;
+                const long long grid = n_s + (tiles_total - n_s + 1) / 2;
+                p.sl_k = k;
+                CARD_LAUNCH(r, "card_sample_coop2_kernel", true,
+                            card_sample_coop2_kernel<<<dim3((unsigned)grid), dim3(kCoop2Threads), (size_t)kCoop2LdsFloats * sizeof(float), stream>>>(p));
+            }
+            return CARD_OK;
+        }
+    }
+    const long long cap = (long long)s->num_cu * s->coop_blocks;
+    const long long grid = tiles_total < cap ? tiles_total : cap;
+    CARD_LAUNCH(r, "card_sample_coop_kernel", true,
+                card_sample_coop_kernel<<<dim3((unsigned)grid), dim3(kCoopThreads), (size_t)kCoopLdsFloats * sizeof(float), stream>>>(p));
+    return CARD_OK;
+}
+
+// what guided_small costs per timestep for n chains (n below a cooperative round): one 16-chain tile per CU, then the
+// time-sliced forms up to two 16-chain tiles (5.4 us) and up to two 32-chain tiles per CU
+double guided_small_cost(long long n, long long lone, long long round2) {
+    constexpr double kCostTwo16 = 5.4;
+    if (n <= lone) return kCostLone16;
+    if (n <= 2 * lone) return kCostLone16 + (kCostTwo16 - kCostLone16) * (double)(n - lone) / (double)lone;
+    return kCostTwo16 + (kCostCoopRound - kCostTwo16) * (double)(n - 2 * lone) / (double)(round2 - 2 * lone);
+}
+
+}  // namespace
 
 int guided_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     int arith = r.arith;
@@ -1269,88 +1351,42 @@ int guided_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     const int n_steps = p.t_hi - p.t_lo + 1;
     if (r.plan)      // layers 2-3, the K = 2 update of layer 1, lin4 (VALU), and the hoisted part once per tile and call
         r.plan->executed = 2.0 * kH * (2 * kH) + 2.0 * kH * 2 + 2.0 * kH + 2.0 * kH * 8 * s->nqs / (double)n_steps;
-    // Small batches (the reference's per-minibatch calls).  Measured per 1000 timesteps (tools/bench_small.py): the
-    // cooperative form takes 5.3 ms for up to num_cu tiles and 9.0 ms per round of 2 x num_cu tiles (two workgroups per
-    // CU); the persistent kernel 18.0 ms while every tile has a SIMD to itself (<= 4 x num_cu tiles), 33.8 ms up to
-    // 8 x num_cu tiles.  The cooperative form is ahead up to 3.5 rounds = 7 x num_cu tiles (57 344 chains on 256 CUs).
-    const long long tiles_total = (p.N + kTileM - 1) / kTileM;
-    if (s->coop_blocks > 0 && (s->tune.coop_force || tiles_total <= (long long)kCoopMaxRoundsX2 * s->num_cu)) {
-        p.n_begin = 0;
-        p.n_end = p.N;
-        const bool ybuf_fits = (unsigned long long)p.N * sizeof(float) <= scratch_bytes;   // chain states between time slices
-        // Up to two 16-chain tiles per CU (8 192 chains on 256 CUs; BASELINE configs[0] is 5 100): the 16-chain-tile kernel,
-        // one tile per CU up to num_cu tiles, the time-sliced single / paired scheme between num_cu and 2 x num_cu.
-        // (a CU sharing two 16-chain tiles takes 5.3 us per timestep, one 32-chain tile alone 5.3 us: above 15/8 tiles
-        // per CU the 32-chain form below is as fast)
-        const long long tiles16 = (p.N + kT16 - 1) / kT16;
-        if (s->coop_blocks == 2 && !s->tune.coop_no16 && s->wpk16 && tiles16 <= 2LL * s->num_cu - s->num_cu / 8) {
-            long long n_single = tiles16 <= s->num_cu ? tiles16 : 2LL * s->num_cu - tiles16;
-            int K = 1, S = n_steps, L = n_steps;
-            if (tiles16 > s->num_cu && n_single > 0 && !p.eps_only && n_steps >= 64 && ybuf_fits) {
-                const int K2 = (int)((tiles16 + n_single - 1) / n_single);
-                const int S2 = (int)((double)n_steps / ((double)(K2 - 1) + kRho16) + 0.5);
-                const int L2 = n_steps - (K2 - 1) * S2;
-                if (K2 <= 8 && S2 >= 8 && L2 >= S2) { K = K2; S = S2; L = L2; }
-            }
-            if (K == 1 && tiles16 > s->num_cu) n_single = 2LL * s->num_cu - tiles16 > 0 ? 2LL * s->num_cu - tiles16 : 0;
-            p.ybuf = p.ws;
-            p.sl_K = K; p.sl_nsingle = (int)n_single; p.sl_S = S; p.sl_L = L;
-            for (int k = 0; k < K; ++k) {
-                long long n_s = n_single > 0 ? tiles16 - (long long)k * n_single : 0;
-                n_s = n_s > n_single ? n_single : (n_s < 0 ? 0 : n_s);
-                const long long grid = n_s + (tiles16 - n_s + 1) / 2;
-                p.sl_k = k;
-                CARD_LAUNCH(r, "card_sample_coop16_kernel", true,
-                            card_sample_coop16_kernel<<<dim3((unsigned)grid), dim3(kCoop2Threads), (size_t)kCoop16LdsFloats * sizeof(float), stream>>>(p));
-            }
-            return CARD_OK;
-        }
-        // Between one and two tiles per CU (the reference's Year minibatch: 12 800 chains = 400 tiles): the time-sliced
-        // paired form, see card_sample_coop2_kernel.  n_single CUs' worth of tiles run alone in each slice; every tile
-        // does so in exactly one of the K slices.
-        if (s->coop_blocks == 2 && !s->tune.coop_no2 && !p.eps_only && tiles_total > s->num_cu &&
-            tiles_total < 2LL * s->num_cu && n_steps >= 64 && ybuf_fits) {
-            const long long n_single = 2LL * s->num_cu - tiles_total;
-            const int K = (int)((tiles_total + n_single - 1) / n_single);
-            const int S = (int)((double)n_steps / ((double)(K - 1) + kRho32) + 0.5);
-            const int L = n_steps - (K - 1) * S;
-            if (K <= 8 && S >= 8 && L >= S) {
-                p.ybuf = p.ws;
-                p.sl_K = K; p.sl_nsingle = (int)n_single; p.sl_S = S; p.sl_L = L;
-                for (int k = 0; k < K; ++k) {
-                    long long n_s = tiles_total - (long long)k * n_single;
-                    n_s = n_s > n_single ? n_single : n_s;
-                    const long long grid = n_s + (tiles_total - n_s + 1) / 2;
-                    p.sl_k = k;
-                    CARD_LAUNCH(r, "card_sample_coop2_kernel", true,
-                                card_sample_coop2_kernel<<<dim3((unsigned)grid), dim3(kCoop2Threads), (size_t)kCoop2LdsFloats * sizeof(float), stream>>>(p));
-                }
-                return CARD_OK;
-            }
-        }
-        const long long cap = (long long)s->num_cu * s->coop_blocks;
-        const long long grid = tiles_total < cap ? tiles_total : cap;
-        CARD_LAUNCH(r, "card_sample_coop_kernel", true,
-                    card_sample_coop_kernel<<<dim3((unsigned)grid), dim3(kCoopThreads), (size_t)kCoopLdsFloats * sizeof(float), stream>>>(p));
-        return CARD_OK;
+    // A call is cut into [0, n_pers): whole rounds of the persistent kernel (num_cu * 8 tiles, two waves per SIMD);
+    // [n_pers, n_pers + n_coop): whole rounds of the cooperative kernel (two 32-chain tiles per CU, 9.0 ms per 1000
+    // timesteps and round against 18.0 / 33.6 ms per 4 / 8 tiles per CU on the persistent kernel: ahead up to 3.5
+    // rounds); the rest, less than a cooperative round: the small-batch forms (guided_small).  100 000 chains are one
+    // persistent round + two cooperative rounds + 1 696 chains on 16-chain tiles, 54 ms per 1000 timesteps instead of the
+    // 68 ms of two persistent rounds.  Results do not depend on the cut: the kernels are bit-identical per chain
+    // (tests/test_gpu_sliced.py) and the noise is keyed by the chain's element index.
+    const long long round8 = (long long)s->num_cu * kWaves * kTileM;
+    long long n_pers = p.N, n_coop = 0;
+    if (s->coop_blocks > 0) {
+        const long long round2 = (long long)s->num_cu * s->coop_blocks * kTileM, lone = (long long)s->num_cu * kT16;
+        const long long k8 = p.N / round8, rest = p.N - k8 * round8, m = rest / round2, tail = rest - m * round2;
+        const double c_pers = (rest == 0 ? 0.0 : rest <= round8 / 2 ? kCostPersHalf : kCostPers) * n_steps + (rest && !k8 ? kCostLaunch : 0.0);
+        const double c_coop = ((double)m * kCostCoopRound + (tail ? guided_small_cost(tail, lone, round2) : 0.0)) * n_steps +
+                              ((m ? 1 : 0) + (tail ? 1 : 0)) * kCostLaunch;
+        const double whole = (double)k8 * kCostPers * n_steps + kCostLaunch;
+        if (s->tune.coop_force) n_pers = 0;
+        else if (rest > 0 && c_pers - c_coop >= kPlanMinGain * ((k8 ? whole : 0.0) + c_pers)) n_pers = k8 * round8;
+        n_coop = (p.N - n_pers) / round2 * round2;
     }
-    // Very large N: launches of whole waves-worth of tiles so that one launch stays well under a second and every wave
+    // Persistent kernel: launches of whole waves-worth of tiles so that one launch stays well under a second and every wave
     // gets the same number of tiles (no intra-launch tail except in the last one).
     // in-kernel row tiling with n_z >= 32: the hoisted layer-1 tile has two distinct columns -> LDS-resident form (HOIST = 2)
     const bool two_col = r.n_z >= 32;
-    if (!two_col && r.lib_scratch) {
+    if (n_pers > 0 && !two_col && r.lib_scratch) {
         // only this form needs the per-wave slots, 16 KB per resident wave
         const unsigned long long need = (unsigned long long)s->num_cu * kWaves * kSlotFloats * sizeof(float);
         if (need > r.workspace_bytes)
             return card_fail(CARD_E_UNSUPPORTED, "card_sampler_run_static: %d CUs need %llu bytes of wave slots, the static scratch has %llu",
                              s->num_cu, need, r.workspace_bytes);
     }
-    const long long waves = (long long)s->num_cu * kWaves;
     const long long tiles_per_wave = 16;
-    const long long chunk = waves * tiles_per_wave * kTileM;
-    for (long long b = 0; b < p.N; b += chunk) {
+    const long long chunk = round8 * tiles_per_wave;
+    for (long long b = 0; b < n_pers; b += chunk) {
         p.n_begin = b;
-        p.n_end = b + chunk < p.N ? b + chunk : p.N;
+        p.n_end = b + chunk < n_pers ? b + chunk : n_pers;
         const long long tiles = (p.n_end - p.n_begin + kTileM - 1) / kTileM;
         const long long grid = tiles < s->num_cu ? tiles : s->num_cu;
         if (two_col)
@@ -1358,6 +1394,13 @@ int guided_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
         else
             CARD_LAUNCH(r, "card_sample_guided_kernel<1>", true, card_sample_guided_kernel<1><<<dim3((unsigned)grid), dim3(kThreads), s->lds_bytes, stream>>>(p));
     }
+    if (n_coop > 0) {
+        p.n_begin = n_pers;
+        p.n_end = n_pers + n_coop;
+        CARD_LAUNCH(r, "card_sample_coop_kernel", true,
+                    card_sample_coop_kernel<<<dim3((unsigned)(s->num_cu * s->coop_blocks)), dim3(kCoopThreads), (size_t)kCoopLdsFloats * sizeof(float), stream>>>(p));
+    }
+    if (n_pers + n_coop < p.N) return guided_small(s, r, p, n_pers + n_coop, p.N, scratch_bytes, stream);
     return CARD_OK;
 }
 

@@ -131,3 +131,27 @@ def test_16_chain_tile_kernel_year_width_and_row_tiling(monkeypatch):
         err = max(norm_rel_err(outs[0][k, sl].cpu(), want[k]) for k in range(T + 1))
         print(f"16-chain kernel, row {r}: worst per-state norm-rel err vs oracle {err:.2e}")
         assert err <= TOL
+
+
+@pytest.mark.parametrize("N", [18000, 70000, 100000])
+def test_a_call_cut_into_rounds_of_different_kernels_is_bit_identical(N, monkeypatch):
+    """Above a cooperative round (16 384 chains on 256 CUs) a call is cut into whole rounds of the persistent kernel, whole
+    rounds of the cooperative kernel and a rest on the small-batch forms (card_guided.hip guided_run): same bits as the
+    persistent kernel alone (CARD_AMD_COOP=off), in RNG mode with in-kernel row tiling, and the plan shows the cut."""
+    g = load_golden("reg_boston_T1000")
+    T, n_z = 64, 8
+    coef = make_coef_table(g["alphas"][:T], g["omabs"][:T]).to(DEV)
+    x, y0, mu = _inputs(g, N // n_z, 5)
+    outs, plans = {}, {}
+    for mode in ("", "off"):
+        monkeypatch.setenv("CARD_AMD_COOP", mode)
+        s = Sampler.from_state_dict(g["sd"], device=DEV)
+        outs[mode] = (s.run(x, y0, mu, coef, T, seed=9, elem_offset=3, n_z=n_z),
+                      s.run(x, y0, mu, coef, T, seed=9, elem_offset=3, n_z=n_z, out_mode=_lib.OUT_SELECT, states=[0, 13, T]),
+                      s.run(x, y0, mu, coef, T, seed=9, elem_offset=3, n_z=n_z, static_scratch=True))
+        plans[mode] = s.run(x, y0, mu, coef, T, seed=9, n_z=n_z, plan=True)
+    for a, b in zip(outs[""], outs["off"]):
+        assert torch.equal(a, b) and torch.isfinite(a).all()
+    assert plans["off"]["kernel"].startswith("card_sample_guided_kernel") and plans["off"]["launches"] == 1
+    assert plans[""]["launches"] >= 2
+    assert plans[""]["kernel"].startswith("card_sample_guided_kernel" if N >= 65536 else "card_sample_coop_kernel")
