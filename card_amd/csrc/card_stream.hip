@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kWaves * 64, (kWaves == 8 || SPLIT == 4) ? 2 : 1) v
     for (int i = tid * 4; i < G::TABS; i += kThreads * 4)
         *reinterpret_cast<f32x4*>(tabs + i) = *reinterpret_cast<const f32x4*>(p.tabs + i);
     for (int i = tid; i < G::GROW; i += kThreads) gbuf[i] = p.gtab[(long long)p.t_hi * G::GROW + i];
-    // DIRECT: this wave's A fragment of one k-step, 1 KB: lane l holds features 16 (4 part + e) + (l & 15), e = 0..3
+    // DIRECT: this wave's A fragments of one k-step, NQW x 1 KB: word q, lane l holds output features 16 (4 (NQW part + q) + e) + (l & 15), e = 0..3
     f32x4 frag[DIRECT ? DD : 1][NQW], frag1[DIRECT && L1RES ? KS1 : 1];
     const int voffd = lane * 16 + part * NQW * 1024;
     auto frag_load = [&](int ks, int q) __attribute__((always_inline)) {      // k-step ks of the packed image (slabs of kSlabKs)
