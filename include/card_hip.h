@@ -214,8 +214,9 @@ typedef struct card_plan {
     int32_t struct_bytes;            /* in: sizeof(card_plan) */
     int32_t backend;                 /* 0 hidden-128 regression kernels, 1 GEMM back end, 2 streamed hidden-256 kernel, 3 cooperative classification kernel */
     int32_t launches;                /* kernel launches of the call, all kinds */
-    int32_t dominant_launches;       /* of them, launches of `kernel` */
-    char kernel[96];                 /* the kernel that carries the matrix work (with its form) */
+    int32_t dominant_launches;       /* of them, launches that carry the matrix work (of `kernel` and, in a call cut into rounds, of its other forms) */
+    char kernel[96];                 /* the kernel that carries the matrix work, with its form; a call that is cut into whole
+                                        rounds of several forms names the form of its first, largest segment */
     double flops_per_sample_step;          /* ALGORITHMIC: 2 H (d_in + 2 H + y_dim), SURVEY.md section 8d */
     double flops_executed_per_sample_step; /* what the kernels issue: hoisted layer 1 once per tile and call, K / class padding priced in
                                               (CARD_ARITH_SPLIT_BF16: the bf16 flops of its six partial products) */
