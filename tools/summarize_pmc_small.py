@@ -4,7 +4,13 @@ import collections, csv, glob, json, re, sys
 out, label = sys.argv[1], sys.argv[2]
 res = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.Counter()
-for p in sorted(glob.glob(f"{out}/*/*/*counter_collection.csv")):
+import os
+newest = {}
+for p in glob.glob(f"{out}/*/*/*counter_collection.csv"):      # one file per pass: the newest
+    k = p.split("/")[-3]
+    if k not in newest or os.path.getmtime(p) > os.path.getmtime(newest[k]):
+        newest[k] = p
+for p in sorted(newest.values()):
     seen = set()
     for r in csv.DictReader(open(p)):
         mm = re.search(r"card_sample\w+", r["Kernel_Name"])

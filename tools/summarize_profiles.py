@@ -14,7 +14,7 @@ if os.path.exists("gpurun_out/ubench.txt"):
     open(dst, "w").write(open("gpurun_out/ubench.txt").read() + note)
 
 for name in ("bench", "cifar", "stream", "mnist"):
-    for p in glob.glob(f"gpurun_out/prof_{name}/*/*kernel_stats.csv"):
+    for p in sorted(glob.glob(f"gpurun_out/prof_{name}/*/*kernel_stats.csv"), key=os.path.getmtime)[-1:]:      # the newest run
         rows = list(csv.reader(open(p)))
         keep = [rows[0]] + [r for r in rows[1:] if "card" in r[0] or "wide_" in r[0] or "pack" in r[0]]
         csv.writer(open(f"profiles/{tag}_kernel_stats_{name}.csv", "w")).writerows(keep)
@@ -27,7 +27,8 @@ for name in ("bench", "cifar", "stream", "mnist"):
 def passes(dirname, match):
     """counter sums over the dispatches whose kernel name contains `match`, per PMC pass"""
     out = {}
-    for p in sorted(glob.glob(f"gpurun_out/{dirname}/*/vm/*counter_collection.csv")):
+    # one file per pass: the newest (gpurun_out/ keeps the files of earlier runs of the same script)
+    for p in sorted(glob.glob(f"gpurun_out/{dirname}/*/vm/*counter_collection.csv"), key=os.path.getmtime):
         agg, dur, n = collections.defaultdict(float), 0.0, collections.Counter()
         for r in csv.DictReader(open(p)):
             if match in r["Kernel_Name"]:
