@@ -87,8 +87,8 @@ namespace {
 //        The form stays within 256 registers, so two such workgroups fit a CU (num_cu * 16 < chains <= num_cu * 32) and
 //        cover each other's waits.
 //    (Round-3 forms this replaced, per 1000 timesteps at x_dim 13: the four-wave ring 43.9 ms at 16 384 chains -> 33.5;
-//    a shared tile on the four-wave ring 16.0 ms at 4 096 chains -> 9.9; two shared tiles on an eight-wave ring 20.7 ms at
-//    8 192 chains -> 17.5.)
+//    a shared tile on the four-wave ring 16.0 ms at 4 096 chains -> 9.2; two shared tiles on an eight-wave ring 20.7 ms at
+//    8 192 chains -> 17.2.)
 constexpr int kDirectDepth = 16;
 
 template <int H, int KS1, int kWaves, int SPLIT = 1>
@@ -189,6 +189,16 @@ __global__ __launch_bounds__(kWaves * 64, (kWaves == 8 || SPLIT == 4) ? 2 : 1) v
     const float* const bl = tabs + 4 * g;
     const float* const w4l = tabs + 3 * H + 4 * g;
     const float b4 = tabs[4 * H];
+    // lin4 = four partial dot products over 64 features each (the features of one `part`), added as (q0 + q1) + (q2 + q3),
+    // in every form: a wave that holds a quarter of the features (SPLIT = 4) computes its q and the four waves trade one
+    // float per lane instead of the layer-3 activations, and keeps its W4 slice in registers (16; with all 64 of a whole
+    // tile in registers the one-wave-per-tile direct form measured 1 % slower).
+    f32x4 w4r[SPLIT == 4 ? NTW : 1];
+    if constexpr (SPLIT == 4) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) w4r[j] = lds4(w4l + 16 * (part * NTW + j));
+    }
+    float* const qx = gbuf + 2 * G::GROW + 2 * NT * 256 + lane * 4;      // SPLIT = 4: [lane][part] partial dot products
     const long long n_rows = p.n_end - p.n_begin;
     const long long n_groups = (n_rows + TPW * kTile - 1) / (TPW * kTile);
     const int iters = (int)((n_groups + gridDim.x - 1) / gridDim.x);   // same for every workgroup: barriers inside
@@ -265,9 +275,14 @@ __global__ __launch_bounds__(kWaves * 64, (kWaves == 8 || SPLIT == 4) ? 2 : 1) v
 
             f32x4 acc[NTW];
             float h[4 * NT];
+            [[maybe_unused]] f32x4 gmr[SPLIT == 4 ? NTW : 1];      // SPLIT = 4: the layer's gamma values, read ahead of its MFMAs (a lone wave waits out every LDS read placed next to its use)
             auto load_bias = [&](int layer) {
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) acc[j] = lds4(bl + layer * H + 16 * (part * NTW + j));
+                if constexpr (SPLIT == 4) {
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j) gmr[j] = lds4(gl + layer * H + 16 * (part * NTW + j));
+                }
             };
             // One slab = NKS k-steps: acc[j] += A(slab)[j][ks] * b[OFF + ks].  Ring protocol (3 buffers, ONE barrier per
             // slab, placed mid-slab where every wave has MFMA work on both sides of it):
@@ -325,6 +340,20 @@ __global__ __launch_bounds__(kWaves * 64, (kWaves == 8 || SPLIT == 4) ? 2 : 1) v
                 for (int q = 0; q < NQW; ++q) frag[P % DD][q] = frag_load(pos_ks((P + DD) % DPT), q);
                 __builtin_amdgcn_sched_barrier(0);      // (left alone, the scheduler sinks the requests to two k-steps ahead of their use)
             };
+            // SPLIT = 4, layer 3: softplus and this wave's share of lin4 in one go; the partial sums are traded, not the activations
+            auto epilogue_lin4_split = [&]() -> float {
+                float d = 0.0f;
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    const f32x4 gm = gmr[j];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d = fmaf(softplus_l2(acc[j][r] * gm[r]), w4r[j][r], d);
+                }
+                qx[part] = d;
+                __syncthreads();
+                const f32x4 q = lds4(qx);
+                return (q[0] + q[1]) + (q[2] + q[3]);
+            };
             auto epilogue = [&](int layer) {
                 if constexpr (SPLIT == 1) {
 #pragma unroll
@@ -341,7 +370,7 @@ __global__ __launch_bounds__(kWaves * 64, (kWaves == 8 || SPLIT == 4) ? 2 : 1) v
                     float* const xw = xb + xpar * (NT * 256);
 #pragma unroll
                     for (int j = 0; j < NTW; ++j) {
-                        const f32x4 gm = lds4(gl + layer * H + 16 * (part * NTW + j));
+                        const f32x4 gm = gmr[j];
                         f32x4 v;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = softplus_l2(acc[j][r] * gm[r]);
@@ -392,7 +421,7 @@ __global__ __launch_bounds__(kWaves * 64, (kWaves == 8 || SPLIT == 4) ? 2 : 1) v
                     load_bias(layer);
 #pragma unroll
                     for (int ks = 0; ks < G::KSH; ++ks) kstep_direct(DP1 + (layer - 1) * G::KSH + ks, h[ks]);
-                    epilogue(layer);
+                    if (SPLIT == 1 || layer == 1) epilogue(layer);
                 }
             } else {
                 if constexpr (NS1 >= 1) slab(std::integral_constant<int, (KS1 < 8 ? KS1 : 8)>{}, std::integral_constant<int, 0>{}, xin);
@@ -408,13 +437,24 @@ __global__ __launch_bounds__(kWaves * 64, (kWaves == 8 || SPLIT == 4) ? 2 : 1) v
                     epilogue(layer);
                 }
             }
-            // ---- lin4 (:51): per-lane partial over its 64 features, then across the four lane groups
-            float dot = 0.0f;
+            // ---- lin4 (:51): per-lane partial over its 64 features (four quarter sums), then across the four lane groups
+            float dot;
+            if constexpr (SPLIT == 4) {
+                dot = epilogue_lin4_split();
+            } else {
+                float q[4];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const f32x4 w = lds4(w4l + 16 * j);
+                for (int pq = 0; pq < 4; ++pq) {
+                    float d = 0.0f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dot = fmaf(h[4 * j + r], w[r], dot);
+                    for (int j = pq * (NT / 4); j < (pq + 1) * (NT / 4); ++j) {
+                        const f32x4 w = lds4(w4l + 16 * j);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) d = fmaf(h[4 * j + r], w[r], d);
+                    }
+                    q[pq] = d;
+                }
+                dot = (q[0] + q[1]) + (q[2] + q[3]);
             }
             dot += __shfl_xor(dot, 16, 64);
             dot += __shfl_xor(dot, 32, 64);
@@ -524,21 +564,22 @@ stream_kernel_t stream_kernel_for(int H, int ks1, int waves, int split = 1) {
     return split == 4 ? stream_kernel_pick<kWavesSmall, 4>(ks1) : stream_kernel_pick<kWavesSmall, 1>(ks1);
 }
 
-// dynamic LDS of a form: tables + two gamma rows; + the slab ring (8 waves) or the two activation exchange blocks (shared tile)
+// dynamic LDS of a form: tables + two gamma rows; + the slab ring (8 waves) or the two activation exchange blocks and the
+// lin4 partial sums (shared tile)
 size_t stream_lds_bytes(int H, int waves, int split) {
     const size_t tabs = (size_t)(4 * H + 4 + 2 * 3 * H) * sizeof(float);
     if (waves == kWavesFull) return tabs + (size_t)3 * kSlabKs * (H / 16) * 64 * sizeof(float);
-    return tabs + (split == 4 ? (size_t)2 * (H / 16) * 256 * sizeof(float) : 0);
+    return tabs + (split == 4 ? (size_t)(2 * (H / 16) * 256 + 256) * sizeof(float) : 0);
 }
 
 // A form of the kernel and what one ROUND of it costs (every resident tile advances one timestep), relative to the
 // shared-tile form with one workgroup per CU.  Measured per 1000 timesteps at x_dim 13 (profiles/r03_small_batch_latency_h256.jsonl:
-// 66.0 / 33.5 / 17.7 / 9.9 ms; x_dim 90: 68 / 38.8 / 19.7 / 11.1): ratios of cycle counts of MFMA-bound loops fed from L2,
+// 66.2 / 33.5 / 17.2 / 9.2 ms; x_dim 50: 71.8 / 36.4 / 18.3 / 10.0): ratios of cycle counts of MFMA-bound loops fed from L2,
 // they do not move with the shader clock.
 struct StreamForm { int waves, split, wg_per_cu; double round_cost; };
 struct StreamSeg { int form; long long chains; };
-constexpr double kRound8 = 6.67, kRound4 = 3.38, kRoundS2 = 1.79, kRoundS1 = 1.0;
-constexpr double kLaunchCost = 0.5;      // a launch (~5 us) in the same unit (a shared-tile round is ~9.9 us per timestep)
+constexpr double kRound8 = 7.2, kRound4 = 3.65, kRoundS2 = 1.87, kRoundS1 = 1.0;
+constexpr double kLaunchCost = 0.5;      // a launch (~5 us) in the same unit (a shared-tile round is ~9.2 us per timestep)
 
 // Cheapest cut of `rem` chains into segments of forms f0..nf-1 (ordered by falling round capacity cap[f]): either all of
 // them in rounds of one form, or the whole rounds of a form and the rest in smaller forms.  At most one segment per form.
