@@ -155,3 +155,19 @@ def test_a_call_cut_into_rounds_of_different_kernels_is_bit_identical(N, monkeyp
     assert plans["off"]["kernel"].startswith("card_sample_guided_kernel") and plans["off"]["launches"] == 1
     assert plans[""]["launches"] >= 2
     assert plans[""]["kernel"].startswith("card_sample_guided_kernel" if N >= 65536 else "card_sample_coop_kernel")
+
+
+@pytest.mark.parametrize("N", [16383, 16385, 32769, 57345, 65535, 65537, 81921, 131073])
+def test_round_boundaries_of_the_cut_are_bit_identical(N, monkeypatch):
+    """One chain either side of a round of the cooperative (16 384) and of the persistent kernel (65 536), short calls
+    (no time slicing) and pre-tiled rows: the cut call equals the persistent kernel alone."""
+    g = load_golden("reg_boston_T1000")
+    T = 6
+    coef = make_coef_table(g["alphas"][:T], g["omabs"][:T]).to(DEV)
+    x, y0, mu = _inputs(g, N, 11)
+    outs = []
+    for mode in ("", "off"):
+        monkeypatch.setenv("CARD_AMD_COOP", mode)
+        s = Sampler.from_state_dict(g["sd"], device=DEV)
+        outs.append(s.run(x, y0, mu, coef, T, seed=4, out_mode=_lib.OUT_ALL))
+    assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0]).all()

@@ -170,3 +170,18 @@ def test_tile_split_over_waves_agrees_bit_for_bit(N, monkeypatch, wave_form):
         monkeypatch.setenv("CARD_AMD_STREAM", "nosplit")
         s1 = Sampler.from_state_dict(sd, device=DEV)
         assert torch.equal(a, s1.run(cuda(x[:r]), cuda(y0[:r]), cuda(mu[:r]), coef, T, seed=5, n_z=7))
+
+
+@pytest.mark.parametrize("N", [4095, 4097, 8191, 8193, 16385, 32767, 32769, 36865, 70001])
+def test_round_boundaries_of_the_cut_are_bit_identical(N, monkeypatch):
+    """One chain either side of a round of every form (4 096 / 8 192 / 16 384 / 32 768 chains on 256 CUs): the call cut into
+    rounds (card_stream.hip stream_plan) equals the eight-wave ring form alone, every state."""
+    T = 5
+    sd, x, y0, mu, _, alphas, omabs = _case(13, T, N, 90 + N % 5)
+    coef = cuda(make_coef_table(alphas, omabs))
+    outs = []
+    for env in ("", "big"):
+        monkeypatch.setenv("CARD_AMD_STREAM", env)
+        s = Sampler.from_state_dict(sd, device=DEV)
+        outs.append(s.run(cuda(x), cuda(y0), cuda(mu), coef, T, seed=6, elem_offset=5, out_mode=_lib.OUT_ALL))
+    assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0]).all()
