@@ -128,6 +128,7 @@ void card_tune_from_env(CardTune* t) {
     t->stream_off = env_has("CARD_AMD_STREAM", "off", '0');
     t->stream_big = env_has("CARD_AMD_STREAM", "big");
     t->stream_nosplit = env_has("CARD_AMD_STREAM", "nosplit");
+    t->stream_noslice = env_has("CARD_AMD_STREAM", "noslice");
     t->cls_off = env_has("CARD_AMD_CLSCOOP", "off", '0');
     t->cls_noslice = env_has("CARD_AMD_CLSCOOP", "noslice");
     t->wide_gemmhead = env_has("CARD_AMD_WIDE", "gemmhead");

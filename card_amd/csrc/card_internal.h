@@ -33,13 +33,13 @@ inline bool card_plan_note(CardPlanRec* pl, const char* name, bool dominant) {
 //   CARD_AMD_COOP     regression, hidden 128:  off (0) = persistent kernel for every batch size | force (2) = cooperative
 //                     kernel for every batch size | no16 = no 16-chain-tile form | no2 = no time-sliced paired form
 //   CARD_AMD_STREAM   regression, hidden 256:  off (0) = GEMM back end instead | big = eight-wave ring form only |
-//                     nosplit = never a tile shared by four waves
+//                     nosplit = never a tile shared by four waves | noslice = no time-sliced paired form
 //   CARD_AMD_CLSCOOP  classification, F = 128: off (0) = GEMM back end instead | noslice = no round-robin time slicing
 //   CARD_AMD_WIDE     GEMM back end:           gemmhead = lin4 as a GEMM launch also up to 32 classes | notail = no 64 x 64 tail tiles
 //   CARD_AMD_ARITH    split = CARD_ARITH_SPLIT_BF16 for calls that leave card_run_args.arith at 0
 struct CardTune {
     int coop_off, coop_force, coop_no16, coop_no2;
-    int stream_off, stream_big, stream_nosplit;
+    int stream_off, stream_big, stream_nosplit, stream_noslice;
     int cls_off, cls_noslice;
     int wide_gemmhead, wide_notail;
     int arith_split;

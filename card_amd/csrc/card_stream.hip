@@ -64,6 +64,9 @@ struct StreamParams {
     int T, t_hi, t_lo;
     int x_dim, cat_x, cat_y_pred;
     int out_mode, eps_only, n_z;
+    // time-sliced paired form (kWaves = 8, SPLIT = 4): launch sl_k of a call cut into K slices, see the kernel
+    float* ybuf;          // (n_end - n_begin) chain states handed from one slice to the next
+    int sl_k, sl_nsingle, sl_S, sl_L;
 };
 
 namespace {
@@ -96,8 +99,10 @@ __global__ __launch_bounds__(kWaves * 64, (kWaves == 8 || SPLIT == 4) ? 2 : 1) v
     using G = Geo<H>;
     constexpr int kThreads = kWaves * 64;
     constexpr int NT = G::NT, NQ = G::NQ, NSH = G::NSH, SLAB = G::SLAB;
-    static_assert(SPLIT == 1 || (SPLIT == 4 && kWaves == 4), "a tile belongs to one wave or is shared by the four of a small workgroup");
-    constexpr bool DIRECT = kWaves == 4;
+    static_assert(SPLIT == 1 || SPLIT == 4, "a tile belongs to one wave or is shared by four");
+    constexpr bool PAIR = kWaves == 8 && SPLIT == 4;        // two shared tiles ("halves") per workgroup, time-sliced
+    constexpr bool DIRECT = kWaves == 4 || PAIR;
+    constexpr int HALVES = PAIR ? 2 : 1, kHalfThreads = kThreads / HALVES;
     constexpr bool L1RES = SPLIT == 4 && KS1 <= 4;          // DIRECT: layer-1 fragments stay in registers (else they take their turn in the ring)
     constexpr int DP1 = L1RES ? 0 : KS1;                    // ring positions of layer 1
     constexpr int DPT = DP1 + 2 * G::KSH;                   // ring positions per timestep
@@ -113,14 +118,44 @@ __global__ __launch_bounds__(kWaves * 64, (kWaves == 8 || SPLIT == 4) ? 2 : 1) v
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const wbuf = lds;
     float* const tabs = lds + (DIRECT ? 0 : G::RING * SLAB);
-    float* const gbuf = tabs + G::TABS;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, n = lane & 15;
     const int part = wave % SPLIT, tl = wave / SPLIT;    // which share of which of the workgroup's tiles
-    float* const xb = gbuf + 2 * G::GROW + lane * 4;     // SPLIT = 4: the tile's two activation exchange blocks, + j * 256
+    const int half = PAIR ? tl : 0, htid = PAIR ? (tid & (kHalfThreads - 1)) : tid;
+    float* const gbuf = tabs + G::TABS + half * 2 * G::GROW;                                   // two gamma rows (per half)
+    float* const xb = tabs + G::TABS + HALVES * 2 * G::GROW + half * (2 * NT * 256) + lane * 4;   // SPLIT = 4: the tile's two activation exchange blocks, + j * 256
     int xpar = 0;                                        // ... and which of them the next epilogue uses
+
+    // PAIR: which tile this half advances in this launch, for how many timesteps, from which timestep.  The scheme of
+    // card_sample_coop2_kernel (card_guided.hip): with n_tiles between one and two per CU the call is cut into K launches;
+    // in launch k the tiles [k nsg, (k + 1) nsg) run ALONE in a workgroup for sl_L timesteps (the other half only keeps
+    // the barriers company) while all others share workgroups for sl_S timesteps, (K - 1) sl_S + sl_L = timesteps of the
+    // call; every tile is single in exactly one launch, every CU busy in every launch; chain states cross launches in ybuf.
+    [[maybe_unused]] long long tile = -1;
+    [[maybe_unused]] int quota = 0, n_iter = 0;
+    int th = p.t_hi;
+    [[maybe_unused]] bool first_seg = true, last_seg = true;
+    if constexpr (PAIR) {
+        const long long n_tiles = (p.n_end - p.n_begin + kTile - 1) / kTile;
+        const int k = p.sl_k, nsg = p.sl_nsingle;
+        const long long first_single = (long long)k * nsg;
+        long long n_s = n_tiles - first_single;
+        n_s = n_s < 0 ? 0 : (n_s > nsg ? nsg : n_s);
+        if ((long long)blockIdx.x < n_s) {
+            if (half == 0) { tile = first_single + blockIdx.x; quota = p.sl_L; }
+        } else {
+            const long long j = 2 * ((long long)blockIdx.x - n_s) + half;
+            if (j < n_tiles - n_s) { tile = j < first_single ? j : j + n_s; quota = p.sl_S; }
+        }
+        n_iter = (long long)blockIdx.x < n_s ? p.sl_L : p.sl_S;
+        const int before = k * p.sl_S + ((tile >= 0 && nsg > 0 && tile / nsg < k) ? p.sl_L - p.sl_S : 0);
+        th = p.t_hi - before;
+        first_seg = before == 0;
+        last_seg = th - quota + 1 <= p.t_lo;
+    }
+    const bool active = !PAIR || tile >= 0;
 
     // slabs come through a buffer resource with a scalar offset: no per-lane 64-bit addresses to keep (or spill)
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wimg), 0, NS * SLAB * 4, 0x00020000);
@@ -142,7 +177,7 @@ __global__ __launch_bounds__(kWaves * 64, (kWaves == 8 || SPLIT == 4) ? 2 : 1) v
     // prologue: tables, gamma row of the first step, slab 0 in ring buffer 0, slab 1 in flight
     for (int i = tid * 4; i < G::TABS; i += kThreads * 4)
         *reinterpret_cast<f32x4*>(tabs + i) = *reinterpret_cast<const f32x4*>(p.tabs + i);
-    for (int i = tid; i < G::GROW; i += kThreads) gbuf[i] = p.gtab[(long long)p.t_hi * G::GROW + i];
+    for (int i = htid; i < G::GROW; i += kHalfThreads) gbuf[i] = p.gtab[(long long)th * G::GROW + i];
     // DIRECT: this wave's A fragments of one k-step, NQW x 1 KB: word q, lane l holds output features 16 (4 (NQW part + q) + e) + (l & 15), e = 0..3
     f32x4 frag[DIRECT ? DD : 1][NQW], frag1[DIRECT && L1RES ? KS1 : 1];
     const int voffd = lane * 16 + part * NQW * 1024;
@@ -198,19 +233,19 @@ __global__ __launch_bounds__(kWaves * 64, (kWaves == 8 || SPLIT == 4) ? 2 : 1) v
 #pragma unroll
         for (int j = 0; j < NTW; ++j) w4r[j] = lds4(w4l + 16 * (part * NTW + j));
     }
-    float* const qx = gbuf + 2 * G::GROW + 2 * NT * 256 + lane * 4;      // SPLIT = 4: [lane][part] partial dot products
+    float* const qx = tabs + G::TABS + HALVES * (2 * G::GROW + 2 * NT * 256) + half * 256 + lane * 4;   // SPLIT = 4: [lane][part] partial dot products
     const long long n_rows = p.n_end - p.n_begin;
     const long long n_groups = (n_rows + TPW * kTile - 1) / (TPW * kTile);
-    const int iters = (int)((n_groups + gridDim.x - 1) / gridDim.x);   // same for every workgroup: barriers inside
+    const int iters = PAIR ? 1 : (int)((n_groups + gridDim.x - 1) / gridDim.x);   // same for every workgroup: barriers inside
     const int T = p.T;
     const int draw0 = p.y_init ? (T - p.t_hi) : 0;
     const int slot_base = draw0;
 
     for (int it = 0; it < iters; ++it) {
         const long long group = (long long)it * gridDim.x + blockIdx.x;
-        const long long row = p.n_begin + (group * TPW + tl) * kTile + n;
-        const bool valid = row < p.n_end;                      // workgroups past the end run on clamped chains
-        const long long rc = valid ? row : p.n_end - 1;
+        const long long row = p.n_begin + (PAIR ? (active ? tile : 0) : group * TPW + tl) * kTile + n;
+        const bool valid = active && row < p.n_end;            // workgroups past the end run on clamped chains
+        const long long rc = row < p.n_end ? row : p.n_end - 1;
         const long long rr = p.n_z > 1 ? rc / p.n_z : rc;
         const float mu = p.ytmean[rr];
         const float y0h = p.y0hat[rr];
@@ -244,7 +279,9 @@ __global__ __launch_bounds__(kWaves * 64, (kWaves == 8 || SPLIT == 4) ? 2 : 1) v
             if (slot >= 0 && valid && g == 0 && part == 0) p.out[slot * p.N + row] = v;
         };
         float y;
-        if (p.y_init) {
+        if (PAIR && !first_seg) {
+            y = p.ybuf[rc - p.n_begin];
+        } else if (p.y_init) {
             y = p.y_init[rc];
         } else {
             y = (p.noise ? p.noise[rc] : draw_rng(0)) + mu;    // regression/diffusion_utils.py:109-110
@@ -257,11 +294,19 @@ __global__ __launch_bounds__(kWaves * 64, (kWaves == 8 || SPLIT == 4) ? 2 : 1) v
         asm volatile("" : "+v"(y), "+v"(mu_r));
 #pragma unroll
         for (int s = 0; s < KS1; ++s) asm volatile("" : "+v"(xin[s]));
-        for (int t = p.t_hi; t >= p.t_lo; --t) {
+        const int n_it = PAIR ? n_iter : p.t_hi - p.t_lo + 1;
+        for (int i = 0; i < n_it; ++i) {
+            const int t = th - i;
+            if constexpr (PAIR) {
+                if (!(active && i < quota)) {          // an idle half: the three barriers of a timestep
+                    __syncthreads(); __syncthreads(); __syncthreads();
+                    continue;
+                }
+            }
             // next gamma row: t-1, or t_hi again for the next group of chains
-            const int tn = t > p.t_lo ? t - 1 : p.t_hi;
+            const int tn = PAIR ? (i + 1 < quota ? t - 1 : t) : (t > p.t_lo ? t - 1 : p.t_hi);
             f32x4 gn = {0.f, 0.f, 0.f, 0.f};
-            if (tid < G::GROW / 4) gn = *reinterpret_cast<const f32x4*>(p.gtab + (long long)tn * G::GROW + tid * 4);
+            if (htid < G::GROW / 4) gn = *reinterpret_cast<const f32x4*>(p.gtab + (long long)tn * G::GROW + htid * 4);
             // Everything the tail of the timestep takes from global memory is requested here, unconditionally (from a
             // stand-in address where the mode has no such input): a load behind a branch makes the compiler wait for ALL
             // outstanding loads where the branch rejoins, which drained the weight requests in flight once per timestep.
@@ -414,7 +459,7 @@ __global__ __launch_bounds__(kWaves * 64, (kWaves == 8 || SPLIT == 4) ? 2 : 1) v
                 epilogue(0);
                 // the next gamma row, published here: the two exchange barriers still ahead in this timestep lie between
                 // this store and its readers, and the barrier just passed between the row's last readers and this store
-                if (SPLIT > 1 && tid < G::GROW / 4) *reinterpret_cast<f32x4*>(gbuf + (gcur ^ 1) * G::GROW + tid * 4) = gn;
+                if (SPLIT > 1 && htid < G::GROW / 4) *reinterpret_cast<f32x4*>(gbuf + (gcur ^ 1) * G::GROW + htid * 4) = gn;
                 // ---- layers 2, 3 (:49-50)
 #pragma unroll
                 for (int layer = 1; layer <= 2; ++layer) {
@@ -474,11 +519,14 @@ __global__ __launch_bounds__(kWaves * 64, (kWaves == 8 || SPLIT == 4) ? 2 : 1) v
             // publish the next gamma row (read after the next step's first slab barrier)
             // (DIRECT with a tile per wave has no barrier of its own in the timestep: one here, behind the store; the
             // row's last readers passed the previous timestep's)
-            if (!(DIRECT && SPLIT > 1) && tid < G::GROW / 4) *reinterpret_cast<f32x4*>(gbuf + (gcur ^ 1) * G::GROW + tid * 4) = gn;
+            if (!(DIRECT && SPLIT > 1) && htid < G::GROW / 4) *reinterpret_cast<f32x4*>(gbuf + (gcur ^ 1) * G::GROW + htid * 4) = gn;
             if constexpr (DIRECT && SPLIT == 1) __syncthreads();
             gcur ^= 1;
         }
-        if (p.out_mode == CARD_OUT_LAST && !p.eps_only && valid && g == 0 && part == 0) p.out[row] = y;
+        if (!p.eps_only && valid && g == 0 && part == 0) {
+            if (PAIR && !last_seg) p.ybuf[row - p.n_begin] = y;
+            else if (p.out_mode == CARD_OUT_LAST) p.out[row] = y;
+        }
     }
 }
 
@@ -545,7 +593,7 @@ template <int W, int S>
 stream_kernel_t stream_kernel_pick(int ks1) {
     // (the packed image zero-fills a layer-1 slab beyond d_in and the kernel feeds zeros for columns beyond d_in, so a
     // model packed for two k-steps also runs, with the same results, on the kernel that walks four)
-    constexpr bool direct = W == kWavesSmall;
+    constexpr bool direct = W == kWavesSmall || S == 4;
     if (direct && ks1 == 2) ks1 = 4;
     switch (ks1) {
         case 2: if constexpr (!direct) return card_sample_stream_kernel<256, 2, W, S>; else return nullptr;
@@ -560,7 +608,7 @@ stream_kernel_t stream_kernel_pick(int ks1) {
 // waves per workgroup (8: slab ring | 4: fragments straight from L2) and, with 4, waves per tile (1 | 4)
 stream_kernel_t stream_kernel_for(int H, int ks1, int waves, int split = 1) {
     if (H != 256) return nullptr;
-    if (waves == kWavesFull) return split == 1 ? stream_kernel_pick<kWavesFull, 1>(ks1) : nullptr;
+    if (waves == kWavesFull) return split == 1 ? stream_kernel_pick<kWavesFull, 1>(ks1) : stream_kernel_pick<kWavesFull, 4>(ks1);
     return split == 4 ? stream_kernel_pick<kWavesSmall, 4>(ks1) : stream_kernel_pick<kWavesSmall, 1>(ks1);
 }
 
@@ -568,8 +616,10 @@ stream_kernel_t stream_kernel_for(int H, int ks1, int waves, int split = 1) {
 // lin4 partial sums (shared tile)
 size_t stream_lds_bytes(int H, int waves, int split) {
     const size_t tabs = (size_t)(4 * H + 4 + 2 * 3 * H) * sizeof(float);
+    const size_t xchg = (size_t)(2 * (H / 16) * 256 + 256) * sizeof(float);       // one shared tile's exchange blocks + partial sums
+    if (waves == kWavesFull && split == 4) return (size_t)(4 * H + 4) * sizeof(float) + 2 * ((size_t)2 * 3 * H * sizeof(float) + xchg);   // two halves
     if (waves == kWavesFull) return tabs + (size_t)3 * kSlabKs * (H / 16) * 64 * sizeof(float);
-    return tabs + (split == 4 ? (size_t)(2 * (H / 16) * 256 + 256) * sizeof(float) : 0);
+    return tabs + (split == 4 ? xchg : 0);
 }
 
 // A form of the kernel and what one ROUND of it costs (every resident tile advances one timestep), relative to the
@@ -579,33 +629,68 @@ size_t stream_lds_bytes(int H, int waves, int split) {
 struct StreamForm { int waves, split, wg_per_cu; double round_cost; };
 struct StreamSeg { int form; long long chains; };
 constexpr double kRound8 = 7.2, kRound4 = 3.65, kRoundS2 = 1.87, kRoundS1 = 1.0;
+constexpr double kRhoPair = 1.90;        // timestep of two shared tiles in one paired workgroup / of a tile alone on its CU
 constexpr double kLaunchCost = 0.5;      // a launch (~5 us) in the same unit (a shared-tile round is ~9.2 us per timestep)
 
-// Cheapest cut of `rem` chains into segments of forms f0..nf-1 (ordered by falling round capacity cap[f]): either all of
-// them in rounds of one form, or the whole rounds of a form and the rest in smaller forms.  At most one segment per form.
-double stream_plan(const StreamForm* forms, int nf, const long long* cap, long long rem, int f0, int steps, StreamSeg* out, int* n_out) {
+// Can [`chains`] be run as the time-sliced paired form (between one and two shared tiles per CU)?  K, S, L: its launches,
+// the timesteps of a paired / of the single launch of a tile.
+bool stream_sliceable(long long chains, int num_cu, int n_steps, int* K, int* S, int* L) {
+    const long long tiles = (chains + kTile - 1) / kTile, n_single = 2LL * num_cu - tiles;
+    if (tiles <= num_cu || n_single < num_cu / 8 || n_steps < 64) return false;
+    *K = (int)((tiles + n_single - 1) / n_single);
+    *S = (int)((double)n_steps / ((double)(*K - 1) + kRhoPair) + 0.5);
+    *L = n_steps - (*K - 1) * *S;
+    return *K <= 8 && *S >= 8 && *L >= *S;
+}
+
+// Cheapest cut of N chains into segments: whole rounds of the forms (ordered by falling round capacity cap[f]; forms[f].waves
+// == 0: not available) and one rest, which runs as a partial round of any form or, where `slice_ok` and stream_sliceable,
+// time-sliced on the paired form (recorded as a segment of form `f_pair`, the two-workgroups-per-CU form, which the run
+// loop slices).  Exhaustive over a handful of round counts.
+double stream_plan(const StreamForm* forms, int nf, const long long* cap, long long N, int steps, bool slice_ok, int f_pair, int num_cu,
+                   StreamSeg* out, int* n_out) {
     double best = 1e300;
     *n_out = 0;
-    for (int g = f0; g < nf; ++g) {
-        const long long whole = rem / cap[g], rest = rem - whole * cap[g];
-        const double all = (double)(whole + (rest ? 1 : 0)) * forms[g].round_cost * steps + kLaunchCost;
-        if (all < best) {
-            best = all;
-            out[0] = {g, rem};
-            *n_out = 1;
-        }
-        if (whole >= 1 && rest > 0 && g + 1 < nf) {
-            StreamSeg sub[4];
-            int ns = 0;
-            const double c = (double)whole * forms[g].round_cost * steps + kLaunchCost + stream_plan(forms, nf, cap, rest, g + 1, steps, sub, &ns);
-            if (c < best) {
-                best = c;
-                out[0] = {g, whole * cap[g]};
-                for (int i = 0; i < ns; ++i) out[1 + i] = sub[i];
-                *n_out = 1 + ns;
-            }
-        }
-    }
+    const int kmax[4] = {0, 2, 1, 2};       // rounds tried of forms 1..3; form 0 (the largest): what fits, or one less
+    const long long K0 = N / cap[0];
+    int k[4];
+    for (k[0] = (int)(K0 > 0 ? K0 - 1 : 0); k[0] <= (int)K0; ++k[0])
+        for (k[1] = 0; k[1] <= (nf > 1 ? kmax[1] : 0); ++k[1])
+            for (k[2] = 0; k[2] <= (nf > 2 ? kmax[2] : 0); ++k[2])
+                for (k[3] = 0; k[3] <= (nf > 3 ? kmax[3] : 0); ++k[3]) {
+                    long long used = 0;
+                    double cost = 0.0;
+                    for (int f = 0; f < nf; ++f) {
+                        used += (long long)k[f] * cap[f];
+                        if (k[f]) cost += (double)k[f] * forms[f].round_cost * steps + kLaunchCost;
+                    }
+                    if (used > N) continue;
+                    const long long rest = N - used;
+                    int rest_form = -1;
+                    double rest_cost = 0.0;
+                    if (rest > 0) {
+                        rest_cost = 1e300;
+                        for (int g = 0; g < nf; ++g) {
+                            // (equal costs: the rest on the smallest form that holds it, whole rounds on the larger ones)
+                            const double c = (double)((rest + cap[g] - 1) / cap[g]) * forms[g].round_cost * steps + kLaunchCost + 1e-9 * (double)cap[g];
+                            if (c < rest_cost) { rest_cost = c; rest_form = g; }
+                        }
+                        int K, S, L;
+                        if (slice_ok && f_pair >= 0 && stream_sliceable(rest, num_cu, steps, &K, &S, &L)) {
+                            // K launches of L timesteps each at the pace of a lone tile (+ 10 % for the paired workgroups' lockstep)
+                            const double c = 1.1 * (double)K * L * kRoundS1 + K * kLaunchCost;
+                            if (c < rest_cost) { rest_cost = c; rest_form = f_pair; }
+                        }
+                    }
+                    if (cost + rest_cost < best) {
+                        best = cost + rest_cost;
+                        int n = 0;
+                        for (int f = 0; f < nf; ++f)
+                            if (k[f]) out[n++] = {f, (long long)k[f] * cap[f]};
+                        if (rest > 0) out[n++] = {rest_form, rest};
+                        *n_out = n;
+                    }
+                }
     return best;
 }
 
@@ -634,6 +719,10 @@ int stream_create(card_sampler* s, const card_model_desc* d, hipStream_t stream)
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)stream_kernel_for(H, ks1, kWavesSmall, 4), kWavesSmall * 64,
                                                          stream_lds_bytes(H, kWavesSmall, 4)));
     s->coop_blocks = occ < 1 ? 1 : occ > 2 ? 2 : occ;
+    // the time-sliced paired form: 84 KB of LDS, chain states between its launches (at most two tiles per CU)
+    HIP_TRY(hipFuncSetAttribute((const void*)stream_kernel_for(H, ks1, kWavesFull, 4), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)stream_lds_bytes(H, kWavesFull, 4)));
+    HIP_TRY(hipMalloc(&s->ws, (size_t)2 * s->num_cu * kTile * sizeof(float)));
     stream_pack_kernel<<<512, 256, 0, stream>>>(d->W[0], d->W[1], d->W[2], H, d_in, ns1, s->wpk);
     stream_tabs_kernel<<<1, 256, 0, stream>>>(d->b[0], d->b[1], d->b[2], d->W4, d->b4, H, s->w1s);
     stream_gamma_kernel<<<512, 256, 0, stream>>>(d->gamma[0], d->gamma[1], d->gamma[2], d->n_embed, H, s->gtab);
@@ -645,6 +734,7 @@ void stream_destroy(card_sampler* s) {
     if (s->wpk) (void)hipFree(s->wpk);
     if (s->w1s) (void)hipFree(s->w1s);
     if (s->gtab) (void)hipFree(s->gtab);
+    if (s->ws) (void)hipFree(s->ws);
 }
 
 int stream_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
@@ -675,9 +765,13 @@ int stream_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
     }
     long long cap[4];
     for (int f = 0; f < nf; ++f) cap[f] = (long long)s->num_cu * forms[f].wg_per_cu * (forms[f].waves / forms[f].split) * kTile;
-    StreamSeg seg[4];
-    int nseg = 0;
-    stream_plan(forms, nf, cap, p.N, 0, r.t_hi - r.t_lo + 1, seg, &nseg);
+    StreamSeg seg[6];
+    int nseg = 0, f_pair = -1;
+    for (int f = 0; f < nf; ++f)
+        if (forms[f].split == 4 && forms[f].wg_per_cu == 2) f_pair = f;
+    const int n_steps = r.t_hi - r.t_lo + 1;
+    const bool slice_ok = !s->tune.stream_noslice && !p.eps_only;
+    stream_plan(forms, nf, cap, p.N, n_steps, slice_ok, f_pair, s->num_cu, seg, &nseg);
     if (r.plan)      // layer 1 on MFMA every step with K padded to 4 * ks1 columns, two H x H layers, lin4 (VALU)
         r.plan->executed = 2.0 * s->hidden * (4 * ((forms[seg[0].form].waves == kWavesSmall && s->k1 == 2) ? 4 : s->k1) + 2 * s->hidden) + 2.0 * s->hidden;
     long long b = 0;
@@ -689,6 +783,30 @@ int stream_run(const card_sampler* s, const CardRun& r, hipStream_t stream) {
         // barriers need that) and one launch stays well under a second
         const long long group = f.waves / f.split * kTile, slots = (long long)s->num_cu * f.wg_per_cu;
         const long long chunk = slots * kGroupsPerWg * group, end = b + seg[i].chains;
+        // Between one and two shared tiles per CU (5 000 chains = 313 tiles on 256 CUs): two independent workgroups on 57
+        // CUs and one on the others leave those idle for half of the launch.  The call is cut in TIME instead, as
+        // card_guided.hip does it for hidden 128: K launches of the paired form (two tiles per 8-wave workgroup, one
+        // workgroup per CU), in each of which 2 num_cu - tiles of the tiles run alone for sl_L timesteps and the others in
+        // pairs for sl_S, sl_L = kRhoPair sl_S.  Same arithmetic per chain and timestep: bit-identical.
+        int K, S, L;
+        if (f.split == 4 && f.wg_per_cu == 2 && slice_ok && stream_sliceable(seg[i].chains, s->num_cu, n_steps, &K, &S, &L) &&
+            (!r.lib_scratch || (unsigned long long)seg[i].chains * sizeof(float) <= r.workspace_bytes)) {
+            const long long tiles = (seg[i].chains + kTile - 1) / kTile, n_single = 2LL * s->num_cu - tiles;
+            stream_kernel_t kp = stream_kernel_for(s->hidden, s->k1, kWavesFull, 4);
+            p.n_begin = b; p.n_end = end;
+            p.ybuf = r.lib_scratch ? static_cast<float*>(r.workspace) : s->ws;
+            p.sl_nsingle = (int)n_single; p.sl_S = S; p.sl_L = L;
+            for (int k = 0; k < K; ++k) {
+                long long n_s = tiles - (long long)k * n_single;
+                n_s = n_s > n_single ? n_single : (n_s < 0 ? 0 : n_s);
+                const long long grid = n_s + (tiles - n_s + 1) / 2;
+                p.sl_k = k;
+                CARD_LAUNCH(r, "card_sample_stream_kernel (8 waves, two time-sliced tiles over 4 waves each)", true,
+                            kp<<<dim3((unsigned)grid), dim3(kWavesFull * 64), stream_lds_bytes(s->hidden, kWavesFull, 4), stream>>>(p));
+            }
+            b = end;
+            continue;
+        }
         for (; b < end; b += chunk) {
             p.n_begin = b;
             p.n_end = b + chunk < end ? b + chunk : end;

@@ -185,3 +185,36 @@ def test_round_boundaries_of_the_cut_are_bit_identical(N, monkeypatch):
         s = Sampler.from_state_dict(sd, device=DEV)
         outs.append(s.run(cuda(x), cuda(y0), cuda(mu), coef, T, seed=6, elem_offset=5, out_mode=_lib.OUT_ALL))
     assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0]).all()
+
+
+@pytest.mark.parametrize("N", [4112, 5000, 6144, 7150])
+def test_time_sliced_paired_form_is_bit_identical(N, monkeypatch):
+    """Between one and two shared tiles per CU the call is cut into K launches of the paired form (two tiles per 8-wave
+    workgroup, each tile alone on its CU in one of the launches; chain states cross launches in a buffer): same bits as
+    the un-sliced forms (CARD_AMD_STREAM=noslice) for the last sample, selected states, a segment that starts from a
+    given state, injected noise, in-kernel row tiling and the entry point that allocates nothing."""
+    T = 150
+    sd, x, y0, mu, _, _, _ = _case(13, T, N, 17)
+    alphas, _, omabs = orc.make_schedule("linear", T, 1e-4, 0.02)        # (_case's schedule is made for a dozen timesteps)
+    coef = cuda(make_coef_table(alphas, omabs))
+    gen = torch.Generator().manual_seed(5)
+    noise = cuda(torch.randn(T, N, 1, generator=gen))
+    outs = {}
+    for env in ("", "noslice"):
+        monkeypatch.setenv("CARD_AMD_STREAM", env)
+        s = Sampler.from_state_dict(sd, device=DEV)
+        kw = dict(seed=31, elem_offset=9)
+        last = s.run(cuda(x), cuda(y0), cuda(mu), coef, T, **kw)
+        sel = s.run(cuda(x), cuda(y0), cuda(mu), coef, T, out_mode=_lib.OUT_SELECT, states=[0, 1, 40, 41, 99, T - 1, T], **kw)
+        seg = s.run(cuda(x), cuda(y0), cuda(mu), coef, T, t_hi=120, t_lo=10, y_init=sel[2], **kw)
+        inj = s.run(cuda(x), cuda(y0), cuda(mu), coef, T, noise=noise, out_mode=_lib.OUT_SELECT, states=[T, 77, 3])
+        r7 = N // 7
+        tiled = s.run(cuda(x[:r7]), cuda(y0[:r7]), cuda(mu[:r7]), coef, T, n_z=7, **kw) if r7 * 7 > 4096 else last
+        stat = s.run(cuda(x), cuda(y0), cuda(mu), coef, T, static_scratch=True, **kw)
+        outs[env] = (last, sel, seg, inj, tiled, stat)
+        form = s.run(cuda(x), cuda(y0), cuda(mu), coef, T, plan=True, **kw)
+        assert ("time-sliced" in form["kernel"]) == (env == ""), form
+        assert form["launches"] == (1 if env else (N + 15) // 16 and -(-((N + 15) // 16) // (512 - (N + 15) // 16)))
+    for a, b in zip(outs[""], outs["noslice"]):
+        assert torch.equal(a, b) and torch.isfinite(a).all()
+    assert torch.equal(outs[""][0], outs[""][1][-1]) and torch.equal(outs[""][0], outs[""][5])

@@ -12,7 +12,8 @@ sd = guided_state_dict(x_dim, T, hidden=H)
 alphas, _, omabs = make_schedule("linear", T, 1e-4, 0.02)
 coef = make_coef_table(alphas, omabs).to(dev)
 samplers = {}
-for mode in ("", "nosplit"):
+ALT = os.environ.get("ALT_MODE", "nosplit")      # the form switch of the second column (CARD_AMD_STREAM)
+for mode in ("", ALT):
     os.environ["CARD_AMD_STREAM"] = mode
     samplers[mode] = Sampler.from_state_dict(sd, device=dev)
 flops = 2 * H * (x_dim + 2 + 2 * H + 1)
@@ -29,7 +30,7 @@ for N in [int(v) for v in sys.argv[1:]] or [1024, 2048, 4096, 6144, 8192, 12288,
             s.run(x, y0, y0, coef, T, seed=2 + i)
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 3
-        row["default_ms" if mode == "" else "one_wave_per_tile_ms"] = round(ms, 3)
+        row["default_ms" if mode == "" else ("one_wave_per_tile_ms" if ALT == "nosplit" else ALT + "_ms")] = round(ms, 3)
     row["kernel"] = samplers[""].run(x, y0, y0, coef, T, seed=1, plan=True)["kernel"]
     row["frac_fp32_matrix_peak"] = round(N * T * flops / (row["default_ms"] * 1e-3) / 157.3e12, 4)
     print(json.dumps(row), flush=True)
