@@ -71,7 +71,7 @@ struct StreamParams {
 
 namespace {
 
-// Two forms of one kernel:
+// The forms of one kernel:
 //  * kWaves = 8, a tile per wave (two waves per SIMD): the slab ring described above; every A fragment that enters the CU
 //    is used by eight waves.  Batches above num_cu * 64 chains.
 //  * kWaves = 4 (one wave per SIMD), DIRECT (round 3): no ring.  Below num_cu * 64 chains a workgroup holds at most four
@@ -89,6 +89,8 @@ namespace {
 //        redundantly in all four.  Per output element the FMA chain over k is unchanged: bit-identical to SPLIT = 1.
 //        The form stays within 256 registers, so two such workgroups fit a CU (num_cu * 16 < chains <= num_cu * 32) and
 //        cover each other's waits.
+//      kWaves = 8, SPLIT = 4 (PAIR): two shared tiles ("halves") in one workgroup, one workgroup per CU, for calls between
+//        one and two tiles per CU, which are cut into time slices (see `tile` / `quota` below and stream_run).
 //    (Round-3 forms this replaced, per 1000 timesteps at x_dim 13: the four-wave ring 43.9 ms at 16 384 chains -> 33.5;
 //    a shared tile on the four-wave ring 16.0 ms at 4 096 chains -> 9.2; two shared tiles on an eight-wave ring 20.7 ms at
 //    8 192 chains -> 17.2.)
