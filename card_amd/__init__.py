@@ -23,4 +23,4 @@ from .diffusion_utils import (  # noqa: F401
 from .guidance import GuidanceNet, describe_guidance, guidance_for  # noqa: F401
 from .sampler import ModelDescription, Sampler, describe, invalidate, sampler_for, unwrap  # noqa: F401
 
-__version__ = "0.2.1"
+__version__ = "0.3.0"
