@@ -331,13 +331,15 @@ __global__ __launch_bounds__(kThreads, 2) void card_sample_guided_kernel(const R
 
             f32x16 hA[4], hB[4];
             if constexpr (HOIST == 1) {
-                const float* sp = slot;
-                asm volatile("" : "+v"(sp));      // keep the slot reads inside the step loop (no LICM into 64 VGPRs)
-                layer_first_hoisted<256>(sp, a10, hh == 0 ? y : 0.0f, gl, hA);
+                int zero = 0;
+                asm volatile("" : "+v"(zero));    // keep the slot reads inside the step loop (no LICM into 64 VGPRs)
+                layer_first_hoisted<256>(slot + zero, a10, hh == 0 ? y : 0.0f, gl, hA);
             } else {
-                const float* sp = crow + sel * kH;
-                asm volatile("" : "+v"(sp));
-                layer_first_hoisted<8>(sp, a10, hh == 0 ? y : 0.0f, gl, hA);
+                // (the OFFSET is laundered, not the pointer: a pointer that has been through an asm operand is a generic
+                // one and the 16 reads below became flat_load_dwordx4 with a vmcnt(0) wait, not ds_read_b128)
+                int off = sel * kH;
+                asm volatile("" : "+v"(off));
+                layer_first_hoisted<8>(crow + off, a10, hh == 0 ? y : 0.0f, gl, hA);
             }
             layer_hidden(w2l, bl + kH, gl + kH, hA, hB);
             layer_hidden(w3l, bl + 2 * kH, gl + 2 * kH, hB, hA);
@@ -469,14 +471,19 @@ __global__ __launch_bounds__(kCoopThreads, 2) void card_sample_coop_kernel(const
 #pragma unroll
             for (int j = 0; j < 4; ++j) zb[((2 * w + hh) * 4 + j) * kTileM + m] = zz[j];
         };
+        auto draw_lds = [&](int d) -> float { return zb[(((d >> 2) & 7) * 4 + (d & 3)) * kTileM + m]; };
+        // (a select of VALUES: `p.noise ? p.noise[..] : zb[..]` as one load compiles to a select of the two ADDRESSES and a flat_load)
         auto draw = [&](int d) -> float {
-            if (p.noise) return p.noise[(long long)(d - draw0) * p.N + rc];
-            return zb[(((d >> 2) & 7) * 4 + (d & 3)) * kTileM + m];
+            float zl = draw_lds(d);
+            asm volatile("" : "+v"(zl));
+            float zg = 0.0f;
+            if (p.noise) zg = p.noise[(long long)(d - draw0) * p.N + rc];
+            return p.noise ? zg : zl;
         };
-        auto store_state = [&](int s, float v) {
+        auto store_state = [&](int s, float v, int selected) {
             long long slot;
             if (p.out_mode == CARD_OUT_ALL) slot = s - slot_base;
-            else if (p.out_mode == CARD_OUT_SELECT) slot = p.state_slot[s];
+            else if (p.out_mode == CARD_OUT_SELECT) slot = selected;
             else return;
             if (slot >= 0 && valid && hh == 0 && w == 0) p.out[slot * p.N + row] = v;
         };
@@ -489,7 +496,7 @@ __global__ __launch_bounds__(kCoopThreads, 2) void card_sample_coop_kernel(const
             y = p.y_init[rc];
         } else {
             y = draw(0) + mu;                                 // diffusion_utils.py:109-110
-            store_state(0, y);
+            store_state(0, y, p.out_mode == CARD_OUT_SELECT ? p.state_slot[0] : 0);
         }
 
         // publish this wave's 32 x 32 block of activations / gather all 128 features of the tile's chains
@@ -513,6 +520,9 @@ __global__ __launch_bounds__(kCoopThreads, 2) void card_sample_coop_kernel(const
             return acc;
         };
 
+        // (What card_sample_coop16_kernel does at this point -- every load waited for before the loop, the timestep's
+        // global loads unconditional at its head -- measured 0.6 % SLOWER here: with two workgroups per CU the waits are
+        // covered, and every lane requesting the gamma row costs more than it saves.)
         for (int t = p.t_hi; t >= p.t_lo; --t) {
             const bool more = t > p.t_lo;
             f32x4 gn = {0.f, 0.f, 0.f, 0.f};
@@ -553,7 +563,7 @@ __global__ __launch_bounds__(kCoopThreads, 2) void card_sample_coop_kernel(const
                 break;
             }
             y = posterior_update(cf, t, y, mu, eps, z);
-            store_state(T - t, y);
+            store_state(T - t, y, p.out_mode == CARD_OUT_SELECT ? p.state_slot[T - t] : 0);
         }
         if (p.out_mode == CARD_OUT_LAST && !p.eps_only && valid && hh == 0 && w == 0) p.out[row] = y;
         __syncthreads();                                      // the next tile rewrites the gamma buffer and red[]
@@ -669,14 +679,19 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop2_kernel(con
 #pragma unroll
         for (int j = 0; j < 4; ++j) zb[((2 * w + hh) * 4 + j) * kTileM + m] = zz[j];
     };
+    auto draw_lds = [&](int d) -> float { return zb[(((d >> 2) & 7) * 4 + (d & 3)) * kTileM + m]; };
+    // (a select of VALUES: `p.noise ? p.noise[..] : zb[..]` as one load compiles to a select of the two ADDRESSES and a flat_load)
     auto draw = [&](int d) -> float {
-        if (p.noise) return p.noise[(long long)(d - draw0) * p.N + rc];
-        return zb[(((d >> 2) & 7) * 4 + (d & 3)) * kTileM + m];
+        float zl = draw_lds(d);
+        asm volatile("" : "+v"(zl));
+        float zg = 0.0f;
+        if (p.noise) zg = p.noise[(long long)(d - draw0) * p.N + rc];
+        return p.noise ? zg : zl;
     };
-    auto store_state = [&](int s, float v) {
+    auto store_state = [&](int s, float v, int selected) {
         long long slot;
         if (p.out_mode == CARD_OUT_ALL) slot = s - slot_base;
-        else if (p.out_mode == CARD_OUT_SELECT) slot = p.state_slot[s];
+        else if (p.out_mode == CARD_OUT_SELECT) slot = selected;
         else return;
         if (slot >= 0 && valid && hh == 0 && w == 0) p.out[slot * p.N + row] = v;
     };
@@ -693,7 +708,7 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop2_kernel(con
             y = p.y_init[rc];
         } else {
             y = draw(0) + mu;                                 // diffusion_utils.py:109-110
-            store_state(0, y);
+            store_state(0, y, p.out_mode == CARD_OUT_SELECT ? p.state_slot[0] : 0);
         }
     }
     int gcur = 0;
@@ -718,26 +733,37 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop2_kernel(con
         return acc;
     };
 
+    // (see card_sample_coop16_kernel: every load so far is waited for here, and what a timestep takes from global memory
+    // is requested unconditionally at its head and first touched where it is used)
+    float mu_r = mu;
+    asm volatile("" : "+v"(y), "+v"(mu_r));
+#pragma unroll
+    for (int i = 0; i < 64; i += 8) {
+        asm volatile("" : "+v"(A2[i]), "+v"(A2[i + 1]), "+v"(A2[i + 2]), "+v"(A2[i + 3]), "+v"(A2[i + 4]), "+v"(A2[i + 5]), "+v"(A2[i + 6]), "+v"(A2[i + 7]));
+        asm volatile("" : "+v"(A3[i]), "+v"(A3[i + 1]), "+v"(A3[i + 2]), "+v"(A3[i + 3]), "+v"(A3[i + 4]), "+v"(A3[i + 5]), "+v"(A3[i + 6]), "+v"(A3[i + 7]));
+    }
     for (int it = 0; it < n_iter; ++it) {
         const bool on = active && it < quota;                 // uniform per wave
-        const int t = th - it;
+        const int t = on ? th - it : p.t_lo;                  // (an idle half requests the rows of a valid timestep)
         const bool more = on && it + 1 < quota;
-        f32x4 gn = {0.f, 0.f, 0.f, 0.f};
         float z = 0.0f;
         f32x16 acc;
-        CoefRow cf = {};
         const float* const gl = gsl + gcur * kGammaRow + 4 * hh;
+        const bool noisy = t >= 1 && !p.eps_only;
+        const float* const crow = (p.eps_only ? p.gtab : p.coef) + (long long)t * CARD_COEF_COLS;
+        f32x4 ca = *reinterpret_cast<const f32x4*>(crow), cb = *reinterpret_cast<const f32x4*>(crow + 4);
+        const f32x4 gn = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(more ? t - 1 : t) * kGammaRow + (htid < kGammaRow / 4 ? htid : 0) * 4);
+        float zin = *(p.noise && noisy ? p.noise + (long long)(T - t - draw0) * p.N + rc : p.ytmean + rr);
+        int slot_sel = *(p.out_mode == CARD_OUT_SELECT ? p.state_slot + (T - t) : reinterpret_cast<const int*>(p.wpk));
         if (on) {
-            if (!p.eps_only) cf = load_coef(p.coef, t);
-            if (more && htid < kGammaRow / 4) gn = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(t - 1) * kGammaRow + htid * 4);
-            if (t >= 1 && !p.eps_only) zfill(T - t);
+            if (noisy) zfill(T - t);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a10, hh == 0 ? y : 0.0f, c1, 0, 0, 0);
             epilogue_tile(acc, gl, w);
             publish(acc, 0);
         }
         __syncthreads();
         if (on) {
-            z = t >= 1 && !p.eps_only ? draw(T - t) : 0.0f;
+            z = noisy ? draw_lds(T - t) : 0.0f;               // (RNG mode's normal; injected noise is `zin`)
             acc = hidden(A2, 0, 1, gl);
             publish(acc, 1);
         }
@@ -762,8 +788,11 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop2_kernel(con
             if (p.eps_only) {
                 if (valid && hh == 0 && w == 0) p.out[row] = eps;
             } else {
-                y = posterior_update(cf, t, y, mu, eps, z);
-                store_state(T - t, y);
+                asm volatile("" : "+v"(ca), "+v"(cb), "+v"(zin), "+v"(slot_sel));      // first touched here (see the head of the loop)
+                const CoefRow cf = {ca[CARD_COEF_INV_SQRT_AB], ca[CARD_COEF_ONE_M_SQRT_AB], ca[CARD_COEF_SOMAB], ca[CARD_COEF_G0],
+                                    cb[CARD_COEF_G1 - 4], cb[CARD_COEF_G2 - 4], cb[CARD_COEF_SIGMA - 4]};
+                y = posterior_update(cf, t, y, mu_r, eps, p.noise ? zin : z);
+                store_state(T - t, y, slot_sel);
             }
         }
     }
@@ -955,14 +984,19 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
 #pragma unroll
         for (int j = 0; j < 4; ++j) zb[((4 * w + g) * 4 + j) * kT16 + n] = zz[j];
     };
+    auto draw_lds = [&](int d) -> float { return zb[(((d >> 2) & 15) * 4 + (d & 3)) * kT16 + n]; };
+    // (a select of VALUES: `p.noise ? p.noise[..] : zb[..]` as one load compiles to a select of the two ADDRESSES and a flat_load)
     auto draw = [&](int d) -> float {
-        if (p.noise) return p.noise[(long long)(d - draw0) * p.N + rc];
-        return zb[(((d >> 2) & 15) * 4 + (d & 3)) * kT16 + n];
+        float zl = draw_lds(d);
+        asm volatile("" : "+v"(zl));
+        float zg = 0.0f;
+        if (p.noise) zg = p.noise[(long long)(d - draw0) * p.N + rc];
+        return p.noise ? zg : zl;
     };
-    auto store_state = [&](int s, float v) {
+    auto store_state = [&](int s, float v, int selected) {
         long long slot;
         if (p.out_mode == CARD_OUT_ALL) slot = s - slot_base;
-        else if (p.out_mode == CARD_OUT_SELECT) slot = p.state_slot[s];
+        else if (p.out_mode == CARD_OUT_SELECT) slot = selected;
         else return;
         if (slot >= 0 && valid && g == 0 && w == 0) p.out[slot * p.N + row] = v;
     };
@@ -979,7 +1013,7 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
             y = p.y_init[rc];
         } else {
             y = draw(0) + mu;                                 // diffusion_utils.py:109-110
-            store_state(0, y);
+            store_state(0, y, p.out_mode == CARD_OUT_SELECT ? p.state_slot[0] : 0);
         }
     }
     int gcur = 0;
@@ -1022,23 +1056,42 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
         epilogue16(acc, gm);
     };
 
+    // Every load issued so far is waited for HERE: a value still in flight at the head of the timestep loop is waited for
+    // inside it, timestep after timestep (vmcnt(N) at each use of a weight register, together with whatever the timestep
+    // itself has requested by then).
+    float mu_r = mu;
+    asm volatile("" : "+v"(y), "+v"(mu_r));
+#pragma unroll
+    for (int i = 0; i < 64; i += 8) {
+        asm volatile("" : "+v"(A2[i]), "+v"(A2[i + 1]), "+v"(A2[i + 2]), "+v"(A2[i + 3]), "+v"(A2[i + 4]), "+v"(A2[i + 5]), "+v"(A2[i + 6]), "+v"(A2[i + 7]));
+        asm volatile("" : "+v"(A3[i]), "+v"(A3[i + 1]), "+v"(A3[i + 2]), "+v"(A3[i + 3]), "+v"(A3[i + 4]), "+v"(A3[i + 5]), "+v"(A3[i + 6]), "+v"(A3[i + 7]));
+    }
+
     for (int it = 0; it < n_iter; ++it) {
 #ifdef CARD_COOP16_PROFILE
         long long pts[8];
 #endif
         PROF16(0);
         const bool on = active && it < quota;
-        const int t = th - it;
+        const int t = on ? th - it : p.t_lo;          // (an idle half requests the rows of a valid timestep)
         const bool more = on && it + 1 < quota;
-        f32x4 gn = {0.f, 0.f, 0.f, 0.f};
         float z = 0.0f;
         f32x4 acc[2];
-        CoefRow cf = {};
         const float* const gl = gsl + gcur * kGammaRow + 4 * g;
+        // Everything the timestep takes from global memory is requested here, unconditionally (from a stand-in address
+        // where the mode has no such input), and first touched where it is used: a load behind a branch is waited for --
+        // with every other load in flight -- where the branch rejoins, i.e. the coefficient row cost a lone tile an L2
+        // round trip at the head of every timestep.
+        const float* const crow = (p.eps_only ? p.gtab : p.coef) + (long long)t * CARD_COEF_COLS;
+        f32x4 ca = *reinterpret_cast<const f32x4*>(crow), cb = *reinterpret_cast<const f32x4*>(crow + 4);
+        // (every lane loads: behind `if (htid < kGammaRow / 4)` the load is one the compiler cannot count, and its next
+        // register-reuse wait falls one short -- on the coefficient row just requested)
+        const f32x4 gn = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(more ? t - 1 : t) * kGammaRow + (htid < kGammaRow / 4 ? htid : 0) * 4);
+        const bool noisy = t >= 1 && !p.eps_only;
+        float zin = *(p.noise && noisy ? p.noise + (long long)(T - t - draw0) * p.N + rc : p.ytmean + rr);
+        int slot_sel = *(p.out_mode == CARD_OUT_SELECT ? p.state_slot + (T - t) : reinterpret_cast<const int*>(p.wpk));
         if (on) {
-            if (!p.eps_only) cf = load_coef(p.coef, t);
-            if (more && htid < kGammaRow / 4) gn = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(t - 1) * kGammaRow + htid * 4);
-            if (t >= 1 && !p.eps_only) zfill(T - t);
+            if (noisy) zfill(T - t);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -1050,7 +1103,7 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
         __syncthreads();
         PROF16(2);
         if (on) {
-            z = t >= 1 && !p.eps_only ? draw(T - t) : 0.0f;
+            z = noisy ? draw_lds(T - t) : 0.0f;          // (RNG mode's normal; injected noise is `zin`)
             hidden(A2, 0, 1, gl, bias2, acc);
             publish(acc, 1);
         }
@@ -1096,8 +1149,11 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
             if (p.eps_only) {
                 if (valid && g == 0 && w == 0) p.out[row] = eps;
             } else {
-                y = posterior_update(cf, t, y, mu, eps, z);
-                store_state(T - t, y);
+                asm volatile("" : "+v"(ca), "+v"(cb), "+v"(zin), "+v"(slot_sel));      // first touched here (see the head of the loop)
+                const CoefRow cf = {ca[CARD_COEF_INV_SQRT_AB], ca[CARD_COEF_ONE_M_SQRT_AB], ca[CARD_COEF_SOMAB], ca[CARD_COEF_G0],
+                                    cb[CARD_COEF_G1 - 4], cb[CARD_COEF_G2 - 4], cb[CARD_COEF_SIGMA - 4]};
+                y = posterior_update(cf, t, y, mu_r, eps, p.noise ? zin : z);
+                store_state(T - t, y, slot_sel);
             }
         }
 #ifdef CARD_COOP16_PROFILE
@@ -1240,7 +1296,7 @@ void guided_destroy(card_sampler* s) {
 // memory beyond LDS / registers (weights in registers or LDS, gamma rows prefetched a step ahead), so it does not move
 // with the shader clock or with HBM speed; it would move with the MFMA issue rate of another chip generation.
 // Measured on MI355X, tools/bench_small.py (profiles/r03_small_batch_ab.jsonl):
-constexpr double kRho16 = 1.68;    // 16-chain tiles: timestep of two tiles sharing a CU (5.27 us) / of one tile alone with every CU busy (3.14 us)
+constexpr double kRho16 = 1.74;    // 16-chain tiles: timestep of two tiles sharing a CU (5.27 us) / of one tile alone with every CU busy (3.0 us); measured best of 1.68 / 1.74 / 1.80 / 1.86
 constexpr double kRho32 = 1.717;   // 32-chain tiles: 9.1 us / 5.3 us
 // What a timestep of each form costs (us on MI355X, profiles/r03_small_batch_latency.jsonl; used as ratios, see above):
 constexpr double kCostPers = 33.6;       // persistent kernel, a round of num_cu * 8 tiles (two waves per SIMD)
