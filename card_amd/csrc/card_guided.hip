@@ -1301,8 +1301,8 @@ constexpr double kRho32 = 1.717;   // 32-chain tiles: 9.1 us / 5.3 us
 // What a timestep of each form costs (us on MI355X, profiles/r03_small_batch_latency.jsonl; used as ratios, see above):
 constexpr double kCostPers = 33.6;       // persistent kernel, a round of num_cu * 8 tiles (two waves per SIMD)
 constexpr double kCostPersHalf = 18.0;   // ... up to num_cu * 4 tiles (every tile has a SIMD to itself)
-constexpr double kCostCoopRound = 9.0;   // cooperative kernel, a round of two 32-chain tiles per CU
-constexpr double kCostLone16 = 3.1;      // 16-chain tiles, at most one per CU; time-sliced forms in between: linear up to a round
+constexpr double kCostCoopRound = 8.9;   // cooperative kernel, a round of two 32-chain tiles per CU
+constexpr double kCostLone16 = 2.95;     // 16-chain tiles, at most one per CU; time-sliced forms in between: linear up to a round
 constexpr double kCostLaunch = 5.0;      // a launch
 constexpr double kPlanMinGain = 0.03;    // the last partial round of a call leaves the persistent kernel only if that saves this share of the call
 
@@ -1375,7 +1375,7 @@ int guided_small(const card_sampler* s, const CardRun& r, RunParams& p, long lon
 // what guided_small costs per timestep for n chains (n below a cooperative round): one 16-chain tile per CU, then the
 // time-sliced forms up to two 16-chain tiles (5.4 us) and up to two 32-chain tiles per CU
 double guided_small_cost(long long n, long long lone, long long round2) {
-    constexpr double kCostTwo16 = 5.4;
+    constexpr double kCostTwo16 = 5.3;
     if (n <= lone) return kCostLone16;
     if (n <= 2 * lone) return kCostLone16 + (kCostTwo16 - kCostLone16) * (double)(n - lone) / (double)lone;
     return kCostTwo16 + (kCostCoopRound - kCostTwo16) * (double)(n - 2 * lone) / (double)(round2 - 2 * lone);
