@@ -393,25 +393,30 @@ __global__ __launch_bounds__(kThreads, FORM >= 1 ? 2 : 1) void card_sample_cls_c
         PROF_T(0);
         bool on[G], more[G];
         f32x4 gn[G];
-        float z[G][4], cf[G][7] = {};
+        float z[G][4];
+        f32x4 ca[G], cb[G];
         const float* gl[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             on[g] = it < cnt[g];
             more[g] = it + 1 < cnt[g];
             gl[g] = gsl[g] + gcur[g] * kGRow + 4 * hh;
-            gn[g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < 4; ++k) z[g][k] = 0.0f;
+            // This timestep's coefficient row and the next gamma row are requested here UNCONDITIONALLY (an idle slot asks for
+            // the rows of a valid timestep, card_eps_theta for a stand-in address; every lane asks for the gamma row) and first
+            // touched where they are used: behind `if (on)` / `if (!p.eps_only)` the compiler waited for them -- and for every
+            // other load in flight -- where the branch rejoins, an L2 round trip at the head of every timestep
+            // (card_guided.hip, card_sample_coop16_kernel).
+            {
+                const int tq = on[g] ? th[g] - it : th[g];
+                const float* const crow = (p.eps_only ? p.gtab : p.coef) + (long long)tq * CARD_COEF_COLS;
+                ca[g] = *reinterpret_cast<const f32x4*>(crow);
+                cb[g] = *reinterpret_cast<const f32x4*>(crow + 4);
+                gn[g] = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(more[g] ? tq - 1 : tq) * kGRow + (tid < kGRow / 4 ? tid : 0) * 4);
+            }
             if (!on[g]) continue;
             const int t = th[g] - it;
-            if (more[g] && tid < kGRow / 4) gn[g] = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(t - 1) * kGRow + tid * 4);
-            // this timestep's coefficient row (scalar loads, issued a whole timestep ahead of their use)
-            if (!p.eps_only) {                             // (card_eps_theta passes no table)
-                const float* c = p.coef + (long long)t * CARD_COEF_COLS;
-                cf[g][0] = c[CARD_COEF_INV_SQRT_AB]; cf[g][1] = c[CARD_COEF_ONE_M_SQRT_AB]; cf[g][2] = c[CARD_COEF_SOMAB];
-                cf[g][3] = c[CARD_COEF_G0]; cf[g][4] = c[CARD_COEF_G1]; cf[g][5] = c[CARD_COEF_G2]; cf[g][6] = c[CARD_COEF_SIGMA];
-            }
             if (t >= 1 && !p.eps_only) {
                 const int d = T - t;
                 if (p.noise) {
@@ -527,7 +532,9 @@ __global__ __launch_bounds__(kThreads, FORM >= 1 ? 2 : 1) void card_sample_cls_c
                 continue;
             }
             // posterior update per (chain, class), classification/diffusion_utils.py:80-86 (t >= 1) / :98-100 (t == 0)
-            const float ci = cf[g][0], co = cf[g][1], cs = cf[g][2], g0 = cf[g][3], g1 = cf[g][4], g2 = cf[g][5], sg = cf[g][6];
+            asm volatile("" : "+v"(ca[g]), "+v"(cb[g]));        // first touched here (see the head of the loop)
+            const float ci = ca[g][CARD_COEF_INV_SQRT_AB], co = ca[g][CARD_COEF_ONE_M_SQRT_AB], cs = ca[g][CARD_COEF_SOMAB], g0 = ca[g][CARD_COEF_G0];
+            const float g1 = cb[g][CARD_COEF_G1 - 4], g2 = cb[g][CARD_COEF_G2 - 4], sg = cb[g][CARD_COEF_SIGMA - 4];
             if (t >= 1 && !p.noise) {
                 const f32x4 zz = lds4(zbuf[g] + ((T - t) & 3) * kTileM * YL + m * YL + c0);
 #pragma unroll
