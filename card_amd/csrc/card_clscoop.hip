@@ -403,21 +403,8 @@ __global__ __launch_bounds__(kThreads, FORM >= 1 ? 2 : 1) void card_sample_cls_c
             gl[g] = gsl[g] + gcur[g] * kGRow + 4 * hh;
 #pragma unroll
             for (int k = 0; k < 4; ++k) z[g][k] = 0.0f;
-            // This timestep's coefficient row and the next gamma row are requested here UNCONDITIONALLY (an idle slot asks for
-            // the rows of a valid timestep, card_eps_theta for a stand-in address; every lane asks for the gamma row) and first
-            // touched where they are used: behind `if (on)` / `if (!p.eps_only)` the compiler waited for them -- and for every
-            // other load in flight -- where the branch rejoins, an L2 round trip at the head of every timestep
-            // (card_guided.hip, card_sample_coop16_kernel).
-            {
-                const int tq = on[g] ? th[g] - it : th[g];
-                const float* const crow = (p.eps_only ? p.gtab : p.coef) + (long long)tq * CARD_COEF_COLS;
-                ca[g] = *reinterpret_cast<const f32x4*>(crow);
-                cb[g] = *reinterpret_cast<const f32x4*>(crow + 4);
-                gn[g] = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(more[g] ? tq - 1 : tq) * kGRow + (tid < kGRow / 4 ? tid : 0) * 4);
-            }
-            if (!on[g]) continue;
-            const int t = th[g] - it;
-            if (t >= 1 && !p.eps_only) {
+            const int t = on[g] ? th[g] - it : th[g];       // (an idle slot requests the rows of a valid timestep)
+            if (on[g] && t >= 1 && !p.eps_only) {
                 const int d = T - t;
                 if (p.noise) {
 #pragma unroll
@@ -427,6 +414,18 @@ __global__ __launch_bounds__(kThreads, FORM >= 1 ? 2 : 1) void card_sample_cls_c
                     gen_block(g, zblock[g]);              // read after the third barrier of this timestep
                 }
             }
+            // This timestep's coefficient row and the next gamma row are requested here UNCONDITIONALLY (an idle slot and
+            // card_eps_theta ask valid stand-ins; every lane asks for the gamma row) and first touched where they are used: behind
+            // `if (!p.eps_only)` / `if (more && tid < 96)` the compiler waited for them -- and for every other load in flight --
+            // where the branch rejoins, an L2 round trip at the head of every timestep (card_guided.hip,
+            // card_sample_coop16_kernel).  Behind the noise block above for the same reason: its branches rejoin with a wait.
+            {
+                const float* const crow = (p.eps_only ? p.gtab : p.coef) + (long long)t * CARD_COEF_COLS;
+                ca[g] = *reinterpret_cast<const f32x4*>(crow);
+                cb[g] = *reinterpret_cast<const f32x4*>(crow + 4);
+                gn[g] = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(more[g] ? t - 1 : t) * kGRow + (tid < kGRow / 4 ? tid : 0) * 4);
+            }
+            if (!on[g]) continue;
             // layer 1 (model.py:82-87): c1 + W1[:, 0:C] . y_t, BN, softplus, Hadamard with x_feat
             f32x16 acc;
 #pragma unroll
