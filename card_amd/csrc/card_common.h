@@ -38,18 +38,21 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 __device__ __forceinline__ float u01(uint32_t r) { return ((float)(r >> 9) + 0.5f) * 1.1920928955078125e-07f; }
 
-// four standard normals for (element, draw block)
+// four standard normals for (element, draw block).  Box-Muller on the hardware transcendentals: v_log_f32 is log2,
+// v_sin_f32 / v_cos_f32 take revolutions, so sqrt(-2 ln u1) = v_sqrt(v_log(u1) * (-2 ln 2)) and the angle 2 pi u2 is u2
+// itself.  Exhaustively over the 2^23 uniforms u01 can return (tools/ubench/boxmuller.hip, profiles/r03_ubench.txt): the
+// radius within 4.9e-7, sine and cosine within 1.26e-7 of double precision, a normal within 1.5e-6 (the parity test
+// allows 2e-6 against the float64 restatement); 17 instructions per pair where logf / sqrtf / sincospif took ~70.
 __device__ __forceinline__ void philox_normal4(unsigned long long seed, unsigned long long elem, uint32_t block,
                                                float (&z)[4]) {
     uint32_t r[4];
     philox4x32_10((uint32_t)elem, (uint32_t)(elem >> 32), block, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        const float rad = sqrtf(-2.0f * logf(u01(r[2 * p])));
-        float s, c;
-        sincospif(2.0f * u01(r[2 * p + 1]), &s, &c);
-        z[2 * p] = rad * c;
-        z[2 * p + 1] = rad * s;
+        const float rad = __builtin_amdgcn_sqrtf(__builtin_amdgcn_logf(u01(r[2 * p])) * -1.3862943611198906f);
+        const float u2 = u01(r[2 * p + 1]);
+        z[2 * p] = rad * __builtin_amdgcn_cosf(u2);
+        z[2 * p + 1] = rad * __builtin_amdgcn_sinf(u2);
     }
 }
 
