@@ -181,6 +181,24 @@ def test_rng_mode_equals_injected_mode_fed_with_its_own_draws():
     assert torch.isfinite(zc).all()
 
 
+def test_generator_against_the_float64_restatement_on_a_large_sample():
+    """2.4 million normals (the Box-Muller half runs on the hardware log2 / sqrt / sin / cos, card_common.h): every one
+    within 2e-6 of oracle.philox_normal's float64 value -- tools/ubench/boxmuller.hip bounds the error at 1.5e-6 over all
+    2^23 uniforms the generator can produce -- and the sample's moments are a standard normal's."""
+    seed, off, N, D = 0xC0FFEE_0000_0042, (1 << 33) + 12345, 200_000, 12       # the element index crosses 2^32
+    z = torch.empty(D, N, 1, device=DEV)
+    _lib.check(_lib.lib().card_philox_normal(seed, off, N, 0, D, z.data_ptr(), None), "philox")
+    torch.cuda.synchronize()
+    want = orc.philox_noise(seed, D, N, 1, elem_offset=off)
+    got = z.cpu()
+    assert torch.isfinite(got).all()
+    assert float((got - want).abs().max()) < 2e-6
+    v = got.double().reshape(-1)
+    assert abs(float(v.mean())) < 3e-3 and abs(float(v.var()) - 1.0) < 5e-3
+    assert abs(float((v ** 3).mean())) < 1e-2 and abs(float((v ** 4).mean()) - 3.0) < 3e-2
+    assert float(v.abs().max()) > 4.5                                           # the tail is there
+
+
 def test_rng_sharding_invariance_and_seed_sensitivity():
     g = load_golden("reg_boston_T50")
     s = Sampler.from_state_dict(g["sd"], device=DEV)
