@@ -178,7 +178,7 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
     // timesteps of the tile (see kZFloats above)
     int zgrp = -1;
     auto zfill = [&](int d) {                    // uniform over the half
-        if (p.noise || (d >> 6) == zgrp) return;
+        if (__builtin_expect(p.noise || (d >> 6) == zgrp, 1)) return;       // (the refill, once per 64 timesteps, out of line)
         zgrp = d >> 6;
         float zz[4];
         philox_normal4(p.seed, elem, (uint32_t)(16 * zgrp + 4 * w + g), zz);
@@ -194,12 +194,15 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
         if (p.noise) zg = p.noise[(long long)(d - draw0) * p.N + rc];
         return p.noise ? zg : zl;
     };
+    // A lone wave per SIMD pays for every TAKEN branch of its timestep (nothing else to issue while the instruction buffer
+    // refills), so the hot path -- RNG noise, last state only, or a wave that stores nothing -- falls through: the rarer
+    // cases sit out of line behind __builtin_expect.
+    const bool st_wave = w == 0 && p.out_mode != CARD_OUT_LAST && !p.eps_only;      // wave-uniform: this wave stores states
     auto store_state = [&](int s, float v, int selected) {
-        long long slot;
-        if (p.out_mode == CARD_OUT_ALL) slot = s - slot_base;
-        else if (p.out_mode == CARD_OUT_SELECT) slot = selected;
-        else return;
-        if (slot >= 0 && valid && g == 0 && w == 0) p.out[slot * p.N + row] = v;
+        if (__builtin_expect(st_wave, 0)) {
+            const long long slot = p.out_mode == CARD_OUT_ALL ? s - slot_base : selected;
+            if (slot >= 0 && valid && g == 0) p.out[slot * p.N + row] = v;
+        }
     };
     float y = 0.0f;
     if (active) {
@@ -268,6 +271,11 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
         asm volatile("" : "+v"(A3[i]), "+v"(A3[i + 1]), "+v"(A3[i + 2]), "+v"(A3[i + 3]), "+v"(A3[i + 4]), "+v"(A3[i + 5]), "+v"(A3[i + 6]), "+v"(A3[i + 7]));
     }
 
+    // injected noise, or a stand-in address (see the head of the loop): one address form, so no branch around its arithmetic
+    float eps_out = 0.0f;
+    const int grow = lane < kGammaRow / 16 ? (kGammaRow / 16) * w + lane : 0;     // this lane's 16 bytes of a gamma row
+    const float* const zin_base = p.noise ? p.noise + rc : p.ytmean + rr;
+    const long long zin_stride = p.noise ? p.N : 0;
     for (int it = 0; it < n_iter; ++it) {
 #ifdef CARD_COOP16_PROFILE
         long long pts[8];
@@ -287,9 +295,11 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
         f32x4 ca = *reinterpret_cast<const f32x4*>(crow), cb = *reinterpret_cast<const f32x4*>(crow + 4);
         // (every lane loads: behind `if (htid < kGammaRow / 4)` the load is one the compiler cannot count, and its next
         // register-reuse wait falls one short -- on the coefficient row just requested)
-        const f32x4 gn = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(more ? t - 1 : t) * kGammaRow + (htid < kGammaRow / 4 ? htid : 0) * 4);
+        // (a quarter of the row per wave, lanes 0-23: every wave has lanes that store it below, so none of them takes the
+        // branch around an empty store)
+        const f32x4 gn = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(more ? t - 1 : t) * kGammaRow + grow * 4);
         const bool noisy = t >= 1 && !p.eps_only;
-        float zin = *(p.noise && noisy ? p.noise + (long long)(T - t - draw0) * p.N + rc : p.ytmean + rr);
+        float zin = zin_base[(long long)(noisy ? T - t - draw0 : 0) * zin_stride];
         int slot_sel = *(p.out_mode == CARD_OUT_SELECT ? p.state_slot + (T - t) : reinterpret_cast<const int*>(p.wpk));
         if (on) {
             if (noisy) zfill(T - t);
@@ -313,7 +323,7 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
         PROF16(4);
         if (on) {
             hidden(A3, 1, 2, gl, bias3, acc);
-            if (more && htid < kGammaRow / 4) *reinterpret_cast<f32x4*>(gsl + (gcur ^ 1) * kGammaRow + htid * 4) = gn;
+            if (more && lane < kGammaRow / 16) *reinterpret_cast<f32x4*>(gsl + (gcur ^ 1) * kGammaRow + grow * 4) = gn;
             // lin4 in the 32-chain kernels' association: the chain over features 8q + e (q, e ascending) lives on lane
             // groups 0 -> 2 -> 0 -> 2, the one over 8q + 4 + e on 1 -> 3 -> 1 -> 3; each finished chain is added to the other
             // (the hand-over between lanes l and l + 32 is one v_permlane32_swap instead of a ds_bpermute round trip; lane
@@ -347,15 +357,14 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) gm1[mb] = lds4(gsl + gcur * kGammaRow + 4 * g + 32 * w + 16 * mb);
             const float eps = (((red[n] + red[kT16 + n]) + red[2 * kT16 + n]) + red[3 * kT16 + n]) + b4;
-            if (p.eps_only) {
-                if (valid && g == 0 && w == 0) p.out[row] = eps;
-            } else {
-                asm volatile("" : "+v"(ca), "+v"(cb), "+v"(zin), "+v"(slot_sel));      // first touched here (see the head of the loop)
-                const CoefRow cf = {ca[CARD_COEF_INV_SQRT_AB], ca[CARD_COEF_ONE_M_SQRT_AB], ca[CARD_COEF_SOMAB], ca[CARD_COEF_G0],
-                                    cb[CARD_COEF_G1 - 4], cb[CARD_COEF_G2 - 4], cb[CARD_COEF_SIGMA - 4]};
-                y = posterior_update(cf, t, y, mu_r, eps, p.noise ? zin : z);
-                store_state(T - t, y, slot_sel);
-            }
+            // (no branch on eps_only here: such a call is one timestep, its update runs on the stand-in row, is not stored,
+            // and eps leaves the loop in eps_out)
+            eps_out = eps;
+            asm volatile("" : "+v"(ca), "+v"(cb), "+v"(zin), "+v"(slot_sel));      // first touched here (see the head of the loop)
+            const CoefRow cf = {ca[CARD_COEF_INV_SQRT_AB], ca[CARD_COEF_ONE_M_SQRT_AB], ca[CARD_COEF_SOMAB], ca[CARD_COEF_G0],
+                                cb[CARD_COEF_G1 - 4], cb[CARD_COEF_G2 - 4], cb[CARD_COEF_SIGMA - 4]};
+            y = posterior_update(cf, t, y, mu_r, eps, p.noise ? zin : z);
+            store_state(T - t, y, slot_sel);
         }
 #ifdef CARD_COOP16_PROFILE
         PROF16(7);
@@ -366,8 +375,9 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
         }
 #endif
     }
-    if (valid && g == 0 && w == 0 && !p.eps_only) {
-        if (!last_seg) p.ybuf[row - p.n_begin] = y;
+    if (valid && g == 0 && w == 0) {
+        if (p.eps_only) p.out[row] = eps_out;
+        else if (!last_seg) p.ybuf[row - p.n_begin] = y;
         else if (p.out_mode == CARD_OUT_LAST) p.out[row] = y;
     }
 }
