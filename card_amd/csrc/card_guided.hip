@@ -602,7 +602,7 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop2_kernel(con
     }
     int zgrp = -1;
     auto zfill = [&](int d) {                    // uniform over the half; see card_sample_coop_kernel
-        if (p.noise || (d >> 5) == zgrp) return;
+        if (__builtin_expect(p.noise || (d >> 5) == zgrp, 1)) return;       // (the refill, once per 32 timesteps, out of line)
         zgrp = d >> 5;
         float zz[4];
         philox_normal4(p.seed, elem, (uint32_t)(8 * zgrp + 2 * w + hh), zz);
@@ -618,12 +618,13 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop2_kernel(con
         if (p.noise) zg = p.noise[(long long)(d - draw0) * p.N + rc];
         return p.noise ? zg : zl;
     };
+    // (the hot path of a timestep falls through, see card_sample_coop16_kernel: the rarer cases sit out of line)
+    const bool st_wave = w == 0 && p.out_mode != CARD_OUT_LAST && !p.eps_only;      // wave-uniform: this wave stores states
     auto store_state = [&](int s, float v, int selected) {
-        long long slot;
-        if (p.out_mode == CARD_OUT_ALL) slot = s - slot_base;
-        else if (p.out_mode == CARD_OUT_SELECT) slot = selected;
-        else return;
-        if (slot >= 0 && valid && hh == 0 && w == 0) p.out[slot * p.N + row] = v;
+        if (__builtin_expect(st_wave, 0)) {
+            const long long slot = p.out_mode == CARD_OUT_ALL ? s - slot_base : selected;
+            if (slot >= 0 && valid && hh == 0) p.out[slot * p.N + row] = v;
+        }
     };
     float y = 0.0f;
     if (active) {
@@ -672,6 +673,10 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop2_kernel(con
         asm volatile("" : "+v"(A2[i]), "+v"(A2[i + 1]), "+v"(A2[i + 2]), "+v"(A2[i + 3]), "+v"(A2[i + 4]), "+v"(A2[i + 5]), "+v"(A2[i + 6]), "+v"(A2[i + 7]));
         asm volatile("" : "+v"(A3[i]), "+v"(A3[i + 1]), "+v"(A3[i + 2]), "+v"(A3[i + 3]), "+v"(A3[i + 4]), "+v"(A3[i + 5]), "+v"(A3[i + 6]), "+v"(A3[i + 7]));
     }
+    float eps_out = 0.0f;
+    const int grow = lane < kGammaRow / 16 ? (kGammaRow / 16) * w + lane : 0;     // this lane's 16 bytes of a gamma row
+    const float* const zin_base = p.noise ? p.noise + rc : p.ytmean + rr;         // injected noise, or a stand-in address
+    const long long zin_stride = p.noise ? p.N : 0;
     for (int it = 0; it < n_iter; ++it) {
         const bool on = active && it < quota;                 // uniform per wave
         const int t = on ? th - it : p.t_lo;                  // (an idle half requests the rows of a valid timestep)
@@ -682,8 +687,8 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop2_kernel(con
         const bool noisy = t >= 1 && !p.eps_only;
         const float* const crow = (p.eps_only ? p.gtab : p.coef) + (long long)t * CARD_COEF_COLS;
         f32x4 ca = *reinterpret_cast<const f32x4*>(crow), cb = *reinterpret_cast<const f32x4*>(crow + 4);
-        const f32x4 gn = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(more ? t - 1 : t) * kGammaRow + (htid < kGammaRow / 4 ? htid : 0) * 4);
-        float zin = *(p.noise && noisy ? p.noise + (long long)(T - t - draw0) * p.N + rc : p.ytmean + rr);
+        const f32x4 gn = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(more ? t - 1 : t) * kGammaRow + grow * 4);
+        float zin = zin_base[(long long)(noisy ? T - t - draw0 : 0) * zin_stride];
         int slot_sel = *(p.out_mode == CARD_OUT_SELECT ? p.state_slot + (T - t) : reinterpret_cast<const int*>(p.wpk));
         if (on) {
             if (noisy) zfill(T - t);
@@ -700,7 +705,7 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop2_kernel(con
         __syncthreads();
         if (on) {
             acc = hidden(A3, 1, 2, gl);
-            if (more && htid < kGammaRow / 4) *reinterpret_cast<f32x4*>(gsl + (gcur ^ 1) * kGammaRow + htid * 4) = gn;
+            if (more && lane < kGammaRow / 16) *reinterpret_cast<f32x4*>(gsl + (gcur ^ 1) * kGammaRow + grow * 4) = gn;
             float part = 0.0f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -715,19 +720,18 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop2_kernel(con
         if (on) {
             const float eps = (((red[m] + red[kTileM + m]) + red[2 * kTileM + m]) + red[3 * kTileM + m]) + b4;
             gcur ^= more ? 1 : 0;
-            if (p.eps_only) {
-                if (valid && hh == 0 && w == 0) p.out[row] = eps;
-            } else {
-                asm volatile("" : "+v"(ca), "+v"(cb), "+v"(zin), "+v"(slot_sel));      // first touched here (see the head of the loop)
-                const CoefRow cf = {ca[CARD_COEF_INV_SQRT_AB], ca[CARD_COEF_ONE_M_SQRT_AB], ca[CARD_COEF_SOMAB], ca[CARD_COEF_G0],
-                                    cb[CARD_COEF_G1 - 4], cb[CARD_COEF_G2 - 4], cb[CARD_COEF_SIGMA - 4]};
-                y = posterior_update(cf, t, y, mu_r, eps, p.noise ? zin : z);
-                store_state(T - t, y, slot_sel);
-            }
+            // (no branch on eps_only: such a call is one timestep, its update runs on the stand-in row and is not stored)
+            eps_out = eps;
+            asm volatile("" : "+v"(ca), "+v"(cb), "+v"(zin), "+v"(slot_sel));      // first touched here (see the head of the loop)
+            const CoefRow cf = {ca[CARD_COEF_INV_SQRT_AB], ca[CARD_COEF_ONE_M_SQRT_AB], ca[CARD_COEF_SOMAB], ca[CARD_COEF_G0],
+                                cb[CARD_COEF_G1 - 4], cb[CARD_COEF_G2 - 4], cb[CARD_COEF_SIGMA - 4]};
+            y = posterior_update(cf, t, y, mu_r, eps, p.noise ? zin : z);
+            store_state(T - t, y, slot_sel);
         }
     }
-    if (valid && hh == 0 && w == 0 && !p.eps_only) {
-        if (!last_seg) p.ybuf[row - p.n_begin] = y;
+    if (valid && hh == 0 && w == 0) {
+        if (p.eps_only) p.out[row] = eps_out;
+        else if (!last_seg) p.ybuf[row - p.n_begin] = y;
         else if (p.out_mode == CARD_OUT_LAST) p.out[row] = y;
     }
 }
