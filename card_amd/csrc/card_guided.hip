@@ -395,7 +395,7 @@ __global__ __launch_bounds__(kCoopThreads, 2) void card_sample_coop_kernel(const
         // come after the next barrier, and a refill is at least two barriers behind the last read of the old group)
         int zgrp = -1;
         auto zfill = [&](int d) {
-            if (p.noise || (d >> 5) == zgrp) return;
+            if (__builtin_expect(p.noise || (d >> 5) == zgrp, 1)) return;   // (the refill, once per 32 timesteps, out of line)
             zgrp = d >> 5;
             float zz[4];
             philox_normal4(p.seed, elem, (uint32_t)(8 * zgrp + 2 * w + hh), zz);
@@ -411,12 +411,13 @@ __global__ __launch_bounds__(kCoopThreads, 2) void card_sample_coop_kernel(const
             if (p.noise) zg = p.noise[(long long)(d - draw0) * p.N + rc];
             return p.noise ? zg : zl;
         };
+        // (the common cases of a timestep fall through, see card_sample_coop16_kernel: the rarer ones sit out of line)
+        const bool st_wave = w == 0 && p.out_mode != CARD_OUT_LAST;       // wave-uniform: this wave stores states
         auto store_state = [&](int s, float v, int selected) {
-            long long slot;
-            if (p.out_mode == CARD_OUT_ALL) slot = s - slot_base;
-            else if (p.out_mode == CARD_OUT_SELECT) slot = selected;
-            else return;
-            if (slot >= 0 && valid && hh == 0 && w == 0) p.out[slot * p.N + row] = v;
+            if (__builtin_expect(st_wave, 0)) {
+                const long long slot = p.out_mode == CARD_OUT_ALL ? s - slot_base : selected;
+                if (slot >= 0 && valid && hh == 0) p.out[slot * p.N + row] = v;
+            }
         };
         if (!p.y_init) zfill(0);
         // gamma row of the first step (the previous tile's last reads of either buffer are behind its barriers)
@@ -454,10 +455,12 @@ __global__ __launch_bounds__(kCoopThreads, 2) void card_sample_coop_kernel(const
         // (What card_sample_coop16_kernel does at this point -- every load waited for before the loop, the timestep's
         // global loads unconditional at its head -- measured 0.6 % SLOWER here: with two workgroups per CU the waits are
         // covered, and every lane requesting the gamma row costs more than it saves.)
+        const int grow = (kGammaRow / 16) * w + (lane < kGammaRow / 16 ? lane : 0);      // this lane's 16 bytes of a gamma row
         for (int t = p.t_hi; t >= p.t_lo; --t) {
             const bool more = t > p.t_lo;
             f32x4 gn = {0.f, 0.f, 0.f, 0.f};
-            if (more && tid < kGammaRow / 4) gn = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(t - 1) * kGammaRow + tid * 4);
+            // (a quarter of the row per wave, lanes 0-23: no wave branches around an empty load or store)
+            if (more && lane < kGammaRow / 16) gn = *reinterpret_cast<const f32x4*>(p.gtab + (long long)(t - 1) * kGammaRow + grow * 4);
             const bool noisy = t >= 1 && !p.eps_only;
             CoefRow cf = {};
             if (!p.eps_only) cf = load_coef(p.coef, t);
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(kCoopThreads, 2) void card_sample_coop_kernel(const
             __syncthreads();
             acc = hidden(A3, 1, 2, gl);
             // next step's gamma row: written between two barriers of this step, read after the next one
-            if (more && tid < kGammaRow / 4) *reinterpret_cast<f32x4*>(gsl + (gcur ^ 1) * kGammaRow + tid * 4) = gn;
+            if (more && lane < kGammaRow / 16) *reinterpret_cast<f32x4*>(gsl + (gcur ^ 1) * kGammaRow + grow * 4) = gn;
             // lin4: this wave's partial over its 32 features, then the four waves' partials in a fixed order
             float part = 0.0f;
 #pragma unroll
@@ -489,7 +492,7 @@ __global__ __launch_bounds__(kCoopThreads, 2) void card_sample_coop_kernel(const
             const float eps = (((red[m] + red[kTileM + m]) + red[2 * kTileM + m]) + red[3 * kTileM + m]) + b4;
             gcur ^= more ? 1 : 0;
 
-            if (p.eps_only) {
+            if (__builtin_expect(p.eps_only, 0)) {
                 if (valid && hh == 0 && w == 0) p.out[row] = eps;
                 break;
             }
