@@ -248,15 +248,25 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop16_kernel(co
             acc[mb] = bias[mb];
             gm[mb] = lds4(gl + layer * kH + 32 * w + 16 * mb);       // used after the MFMAs
         }
+        // The B operands of a k-group (one ds_read_b128 feeds 8 MFMAs) are read TWO groups ahead: left to itself the
+        // compiler issues each pair of reads right where it waits for them, and a lone wave sits out the LDS latency behind
+        // every sixteenth MFMA (~70 cycles, four times a layer).  sched_barrier keeps the read where it is written.
+        const float* const hb = exr + buf * kT16 * kExLd;
+        f32x4 hq[3];
+        hq[0] = lds4(hb);
+        hq[1] = lds4(hb + 8);
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
-            const f32x4 h = lds4(exr + buf * kT16 * kExLd + 8 * a);
+            if (a + 2 < 8) hq[(a + 2) % 3] = lds4(hb + 8 * (a + 2));
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 h = hq[a % 3];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[4 * a + e], h[e], acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[32 + 4 * a + e], h[e], acc[1], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
         epilogue16(acc, gm);
     };
 
