@@ -29,7 +29,6 @@ namespace {
 // covered by the matrix work instead of being waited out at the head of every epilogue (a lone wave per SIMD hides nothing)
 __device__ __forceinline__ void epilogue16(f32x4 (&acc)[2], const f32x4 (&gm)[2]) {
     float xs[8], e[8];
-    __builtin_amdgcn_s_setprio(kPrioValu);
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
@@ -47,7 +46,6 @@ __device__ __forceinline__ void epilogue16(f32x4 (&acc)[2], const f32x4 (&gm)[2]
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < 8; ++r) acc[r >> 2][r & 3] = __builtin_amdgcn_fmed3f(e[r], xs[r], kSpThresh);
-    __builtin_amdgcn_s_setprio(kPrioMfma);
 }
 
 #ifdef CARD_COOP16_PROFILE
