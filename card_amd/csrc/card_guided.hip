@@ -28,12 +28,16 @@ using namespace card;
 namespace {
 
 // gamma multiply + softplus of one 32-feature x 32-chain accumulator tile, in place
+// PRIO: raise the wave's priority for the epilogue (see kPrioValu).  It pays where the waves sharing a SIMD run independently
+// (the persistent kernel +2 %, two cooperative workgroups on a CU +3 %) and costs 1 % where they meet at the same barriers
+// (the two halves of the paired time-sliced kernels), so those pass false.
+template <bool PRIO = true>
 __device__ __forceinline__ void epilogue_tile(f32x16& acc, const float* gl, int j) {
     // staged over the tile's 16 registers (all multiplies, all exp2, all +1, all log2, all selects): the transcendental
     // pipe is quarter rate with a long result latency, and a per-element chain mul -> exp -> add -> log -> med3 (what
     // the scheduler emits for the obvious loop) stalls on every link
     float xs[16], e[16];
-    __builtin_amdgcn_s_setprio(kPrioValu);
+    if (PRIO) __builtin_amdgcn_s_setprio(kPrioValu);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const f32x4 g = lds4(gl + 32 * j + 8 * q);
@@ -52,7 +56,7 @@ __device__ __forceinline__ void epilogue_tile(f32x16& acc, const float* gl, int 
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = __builtin_amdgcn_fmed3f(e[r], xs[r], kSpThresh);
-    __builtin_amdgcn_s_setprio(kPrioMfma);
+    if (PRIO) __builtin_amdgcn_s_setprio(kPrioMfma);
 }
 
 __device__ __forceinline__ void load_bias(f32x16& acc, const float* bl, int j) {
@@ -663,7 +667,7 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop2_kernel(con
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * i + e], h[e], acc, 0, 0, 0);
         }
-        epilogue_tile(acc, gl + layer * kH, w);
+        epilogue_tile<false>(acc, gl + layer * kH, w);
         return acc;
     };
 
@@ -696,7 +700,7 @@ __global__ __launch_bounds__(kCoop2Threads, 2) void card_sample_coop2_kernel(con
         if (on) {
             if (noisy) zfill(T - t);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a10, hh == 0 ? y : 0.0f, c1, 0, 0, 0);
-            epilogue_tile(acc, gl, w);
+            epilogue_tile<false>(acc, gl, w);
             publish(acc, 0);
         }
         __syncthreads();
