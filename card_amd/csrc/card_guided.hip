@@ -868,7 +868,7 @@ void guided_destroy(card_sampler* s) {
 // with the shader clock or with HBM speed; it would move with the MFMA issue rate of another chip generation.
 // Measured on MI355X, tools/bench_small.py (profiles/r03_small_batch_ab.jsonl):
 constexpr double kRho16 = 1.74;    // 16-chain tiles: timestep of two tiles sharing a CU (5.27 us) / of one tile alone with every CU busy (3.0 us); measured best of 1.68 / 1.74 / 1.80 / 1.86
-constexpr double kRho32 = 1.717;   // 32-chain tiles: 9.1 us / 5.3 us
+constexpr double kRho32 = 1.82;    // 32-chain tiles: measured best of 1.69 / 1.717 / 1.745 / 1.78 / 1.82 / 1.87 after the paired kernel lost its priority changes (10 000 chains 6.85 / 6.75 / 6.67 / 6.62 / 6.57 / 6.58 ms)
 // What a timestep of each form costs (us on MI355X, profiles/r03_small_batch_latency.jsonl; used as ratios, see above):
 constexpr double kCostPers = 33.6;       // persistent kernel, a round of num_cu * 8 tiles (two waves per SIMD)
 constexpr double kCostPersHalf = 18.0;   // ... up to num_cu * 4 tiles (every tile has a SIMD to itself)
